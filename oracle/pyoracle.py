@@ -1,0 +1,198 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h", "oracle_field.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+class Fr(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+    @staticmethod
+    def from_int(x):
+        f = Fr()
+        for i in range(4):
+            f.l[i] = (x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+        return f
+
+    def to_int(self):
+        return sum(int(self.l[i]) << (64 * i) for i in range(4))
+
+
+class Shape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "degree_bits", "rate_bits", "cap_height", "num_queries", "pow_bits", "num_challenges",
+        "arity_bits", "final_poly_bits", "n_cols", "n_perm_z", "n_quotient", "n_pis",
+        "perm_batch_size", "hash_mode", "lookup_bits", "witness_load_range_check")]
+
+
+def fibonacci_shape(degree_bits, num_queries, rate_bits=1, cap_height=4, hash_mode=1, lookup_bits=21,
+                    witness_load_range_check=1):
+    """Fibonacci STARK (test_util/fibonacci_stark.rs:60-61,129-131) under StarkConfig::standard_fast_config
+     with the given FRI overrides."""
+    return Shape(degree_bits=degree_bits, rate_bits=rate_bits, cap_height=cap_height, num_queries=num_queries,
+                 pow_bits=16, num_challenges=2, arity_bits=4, final_poly_bits=5, n_cols=4, n_perm_z=2,
+                 n_quotient=2, n_pis=3, perm_batch_size=1, hash_mode=hash_mode, lookup_bits=lookup_bits,
+                 witness_load_range_check=witness_load_range_check)
+
+
+class Consts(C.Structure):
+    _fields_ = [
+        ("all_round_constants", C.c_uint64 * 360),
+        ("mds_circ", C.c_uint64 * 12),
+        ("mds_diag", C.c_uint64 * 12),
+        ("fast_partial_first_round_constant", C.c_uint64 * 12),
+        ("fast_partial_round_constants", C.c_uint64 * 22),
+        ("fast_partial_round_initial_matrix", (C.c_uint64 * 11) * 11),
+        ("fast_partial_round_w_hats", (C.c_uint64 * 11) * 22),
+        ("fast_partial_round_vs", (C.c_uint64 * 11) * 22),
+        ("bn_c", Fr * 88),
+        ("bn_s", Fr * 392),
+        ("bn_m", (Fr * 4) * 4),
+        ("bn_p", (Fr * 4) * 4),
+    ]
+
+
+class AV(C.Structure):
+    _fields_ = [("v", Fr), ("cell", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB)
+    vp = C.c_void_p
+    L.orc_ctx_new.restype = vp
+    L.orc_ctx_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_ctx_free.argtypes = [vp]
+    L.orc_num_cells.restype = C.c_uint64
+    L.orc_num_cells.argtypes = [vp]
+    L.orc_advice.restype = C.POINTER(Fr)
+    L.orc_advice.argtypes = [vp]
+    L.orc_error.restype = C.c_char_p
+    L.orc_error.argtypes = [vp]
+    L.orc_mock_prover.restype = C.c_int
+    L.orc_mock_prover.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
+    L.orc_scope_dump.restype = C.c_size_t
+    L.orc_scope_dump.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.orc_synth_consts.argtypes = [C.POINTER(Consts), C.c_uint64]
+    L.orc_proof_words.restype = C.c_size_t
+    L.orc_proof_words.argtypes = [C.POINTER(Shape)]
+    L.orc_synth_proof.argtypes = [C.POINTER(Shape), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_verify_stark.restype = C.c_int
+    L.orc_verify_stark.argtypes = [vp, C.POINTER(Shape), C.POINTER(Consts), C.POINTER(C.c_uint64)]
+    frp = C.POINTER(Fr)
+    avp = C.POINTER(AV)
+    sigs = {
+        "orc_load_witness": (AV, [vp, frp]), "orc_load_constant": (AV, [vp, frp]), "orc_load_zero": (AV, [vp]),
+        "orc_add": (AV, [vp, AV, AV]), "orc_mul": (AV, [vp, AV, AV]), "orc_mul_add": (AV, [vp, AV, AV, AV]),
+        "orc_select": (AV, [vp, AV, AV, AV]), "orc_select_from_idx": (AV, [vp, avp, C.c_int, AV]),
+        "orc_idx_to_indicator": (None, [vp, AV, C.c_int, avp]),
+        "orc_select_array_by_indicator": (None, [vp, avp, C.c_int, C.c_int, avp, avp]),
+        "orc_num_to_bits": (None, [vp, AV, C.c_int, avp]), "orc_bits_to_num": (AV, [vp, avp, C.c_int]),
+        "orc_decompose_le": (None, [vp, AV, C.c_int, C.c_int, avp]),
+        "orc_limbs_to_num": (AV, [vp, avp, C.c_int, C.c_int]),
+        "orc_check_less_than_safe": (None, [vp, AV, C.c_uint64]), "orc_range_check": (None, [vp, AV, C.c_int]),
+        "orc_constrain_equal": (None, [vp, AV, AV]),
+        "orc_gl_load_witness": (AV, [vp, C.c_uint64]), "orc_gl_load_constant": (AV, [vp, C.c_uint64]),
+        "orc_gl_reduce": (AV, [vp, AV]), "orc_gl_add": (AV, [vp, AV, AV]), "orc_gl_sub": (AV, [vp, AV, AV]),
+        "orc_gl_mul": (AV, [vp, AV, AV]), "orc_gl_mul_add": (AV, [vp, AV, AV, AV]),
+        "orc_gl_mul_sub": (AV, [vp, AV, AV, AV]), "orc_gl_div": (AV, [vp, AV, AV]), "orc_gl_inv": (AV, [vp, AV]),
+        "orc_gl_exp_from_bits_const_base": (AV, [vp, C.c_uint64, avp, C.c_int]),
+        "orc_gl_exp_power_of_2": (AV, [vp, AV, C.c_int]),
+        "orc_ext_mul": (None, [vp, avp, avp, avp]), "orc_ext_inv": (None, [vp, avp, avp]),
+        "orc_ext_div": (None, [vp, avp, avp, avp]),
+        "orc_gl_poseidon_permute": (None, [vp, C.POINTER(Consts), avp, avp]),
+        "orc_bn_poseidon_permute": (None, [vp, C.POINTER(Consts), avp, avp]),
+        "orc_hash_no_pad": (None, [vp, C.POINTER(Consts), C.c_int, avp, C.c_int, avp]),
+        "orc_two_to_one": (None, [vp, C.POINTER(Consts), C.c_int, avp, avp, avp]),
+        "orc_merkle_verify": (None, [vp, C.POINTER(Consts), C.c_int, avp, C.c_int, avp, C.c_int, AV, avp, C.c_int, avp, C.c_int]),
+        "orc_glf_mul": (C.c_uint64, [C.c_uint64, C.c_uint64]), "orc_glf_inv": (C.c_uint64, [C.c_uint64]),
+        "orc_glf_exp": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+        "orc_glf_primitive_root_of_unity": (C.c_uint64, [C.c_int]),
+        "orc_fr_mul": (None, [frp, frp, frp]), "orc_fr_inv": (None, [frp, frp]), "orc_fr_modulus": (None, [frp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class Ctx:
+    """An oracle context (halo2-base Context restated)."""
+
+    def __init__(self, lookup_bits=21, witness_gen_only=True, track_scopes=False):
+        self.L = lib()
+        self.p = self.L.orc_ctx_new(lookup_bits, 1 if witness_gen_only else 0, 1 if track_scopes else 0)
+
+    def close(self):
+        if self.p:
+            self.L.orc_ctx_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_cells(self):
+        return int(self.L.orc_num_cells(self.p))
+
+    def advice_bytes(self):
+        n = self.num_cells()
+        return C.string_at(self.L.orc_advice(self.p), n * 32)
+
+    def error(self):
+        return self.L.orc_error(self.p).decode()
+
+    def scopes(self):
+        n = self.L.orc_scope_dump(self.p, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.L.orc_scope_dump(self.p, buf, n + 1)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            path, cells = line.rsplit(" ", 1)
+            out[path] = int(cells)
+        return out
+
+    def mock_prover(self):
+        g, e, l, s = (C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64())
+        bad = self.L.orc_mock_prover(self.p, C.byref(g), C.byref(e), C.byref(l), C.byref(s))
+        return dict(bad=bad, gates=g.value, equalities=e.value, lookups=l.value, semantic_failed=s.value)
+
+
+def synth_consts(seed=0xC0FFEE):
+    k = Consts()
+    lib().orc_synth_consts(C.byref(k), seed)
+    return k
+
+
+def synth_proof(shape, seed):
+    n = lib().orc_proof_words(C.byref(shape))
+    buf = (C.c_uint64 * n)()
+    lib().orc_synth_proof(C.byref(shape), seed, buf)
+    return buf
+
+
+def verify_stark(ctx, shape, consts, proof_words):
+    return lib().orc_verify_stark(ctx.p, C.byref(shape), C.byref(consts), proof_words)
