@@ -1,0 +1,190 @@
+"""Host-side mirrors of the reference interface over the C-ABI (include/h2w.h).
+
+`Context` + `NativeChip` + `GoldilocksChip` mirror halo2-base Context / verifier NativeChip
+(verifier/src/field/native.rs) / GoldilocksChip (verifier/src/field/goldilocks/base.rs): same method names,
+argument meaning and error behaviour (a non-zero status raises H2WError where the reference panics).
+`Plan` drives the batched hot path.  torch is used only for device memory / streams.
+"""
+import ctypes as C
+
+from . import (Assigned, Fr, H2WError, PoseidonConsts, Shape, _ck, last_error, lib)
+
+GL_P = 0xFFFFFFFF00000001
+FR_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+class Context:
+    """halo2-base Context as seen through ContextWrapper (util/context_wrapper.rs): an advice stream."""
+
+    def __init__(self, lookup_bits=21, witness_gen_only=True, device_id=0):
+        self.L = lib()
+        self.p = self.L.h2w_ctx_new(lookup_bits, 1 if witness_gen_only else 0, device_id)
+        if not self.p:
+            raise H2WError("h2w_ctx_new: " + last_error())
+        self.lookup_bits = lookup_bits
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.h2w_ctx_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_cells(self):  # ContextWrapper::num_cells
+        return int(self.L.h2w_num_cells(self.p))
+
+    def advice_bytes(self, first=0, count=None):
+        """Expands the pending records on the GPU and returns canonical-LE cells as bytes."""
+        n = self.num_cells() if count is None else count
+        buf = (Fr * max(n, 1))()
+        _ck(self.L.h2w_ctx_download(self.p, first, n, buf), "h2w_ctx_download")
+        return bytes(buf)[: n * 32]
+
+
+def _arr(items):
+    a = (Assigned * len(items))()
+    for i, x in enumerate(items):
+        a[i] = x
+    return a
+
+
+class NativeChip:
+    """verifier/src/field/native.rs:11-194."""
+
+    def __init__(self, ctx):
+        self.ctx, self.L, self.p = ctx, ctx.L, ctx.p
+
+    def _out(self):
+        return Assigned()
+
+    def load_constant(self, a):
+        o = self._out(); _ck(self.L.h2w_load_constant(self.p, C.byref(Fr.from_int(a)), C.byref(o)), "load_constant"); return o
+
+    def load_zero(self):
+        o = self._out(); _ck(self.L.h2w_load_zero(self.p, C.byref(o)), "load_zero"); return o
+
+    def load_constants(self, cs):
+        arr = (Fr * len(cs))(*[Fr.from_int(c) for c in cs]); out = (Assigned * len(cs))()
+        _ck(self.L.h2w_load_constants(self.p, arr, len(cs), out), "load_constants"); return list(out)
+
+    def load_witness(self, a):
+        o = self._out(); _ck(self.L.h2w_load_witness(self.p, C.byref(Fr.from_int(a)), C.byref(o)), "load_witness"); return o
+
+    def add(self, a, b):
+        o = self._out(); _ck(self.L.h2w_add(self.p, C.byref(a), C.byref(b), C.byref(o)), "add"); return o
+
+    def mul(self, a, b):
+        o = self._out(); _ck(self.L.h2w_mul(self.p, C.byref(a), C.byref(b), C.byref(o)), "mul"); return o
+
+    def mul_add(self, a, b, c):
+        o = self._out(); _ck(self.L.h2w_mul_add(self.p, C.byref(a), C.byref(b), C.byref(c), C.byref(o)), "mul_add"); return o
+
+    def select(self, a, b, sel):
+        o = self._out(); _ck(self.L.h2w_select(self.p, C.byref(a), C.byref(b), C.byref(sel), C.byref(o)), "select"); return o
+
+    def select_from_idx(self, arr, idx):
+        o = self._out(); _ck(self.L.h2w_select_from_idx(self.p, _arr(arr), len(arr), C.byref(idx), C.byref(o)), "select_from_idx"); return o
+
+    def select_array_by_indicator(self, array2d, indicator):
+        ln, w = len(array2d), len(array2d[0])
+        flat = _arr([x for row in array2d for x in row]); out = (Assigned * w)()
+        _ck(self.L.h2w_select_array_by_indicator(self.p, flat, ln, w, _arr(indicator), out), "select_array_by_indicator"); return list(out)
+
+    def idx_to_indicator(self, idx, ln):
+        out = (Assigned * ln)(); _ck(self.L.h2w_idx_to_indicator(self.p, C.byref(idx), ln, out), "idx_to_indicator"); return list(out)
+
+    def num_to_bits(self, a, range_bits):
+        out = (Assigned * range_bits)(); _ck(self.L.h2w_num_to_bits(self.p, C.byref(a), range_bits, out), "num_to_bits"); return list(out)
+
+    def bits_to_num(self, bits):
+        o = self._out(); _ck(self.L.h2w_bits_to_num(self.p, _arr(bits), len(bits), C.byref(o)), "bits_to_num"); return o
+
+    def decompose_le(self, num, limb_bits, num_limbs):
+        out = (Assigned * num_limbs)(); _ck(self.L.h2w_decompose_le(self.p, C.byref(num), limb_bits, num_limbs, out), "decompose_le"); return list(out)
+
+    def limbs_to_num(self, limbs, limb_bits):
+        o = self._out(); _ck(self.L.h2w_limbs_to_num(self.p, _arr(limbs), len(limbs), limb_bits, C.byref(o)), "limbs_to_num"); return o
+
+    def check_less_than_safe(self, a, b):
+        _ck(self.L.h2w_check_less_than_safe(self.p, C.byref(a), b), "check_less_than_safe")
+
+    def range_check(self, a, range_bits):
+        _ck(self.L.h2w_range_check(self.p, C.byref(a), range_bits), "range_check")
+
+    def assert_equal(self, a, b):
+        _ck(self.L.h2w_constrain_equal(self.p, C.byref(a), C.byref(b)), "assert_equal")
+
+
+class GoldilocksChip:
+    """verifier/src/field/goldilocks/base.rs:46-466 (fused level: hints run inside the library)."""
+
+    def __init__(self, native):
+        self.native, self.L, self.p = native, native.L, native.p
+
+    def load_constant(self, a):
+        o = Assigned(); _ck(self.L.h2w_gl_load_constant(self.p, a, C.byref(o)), "gl.load_constant"); return o
+
+    def load_witness(self, a):
+        o = Assigned(); _ck(self.L.h2w_gl_load_witness(self.p, a, C.byref(o)), "gl.load_witness"); return o
+
+    def reduce(self, a):
+        o = Assigned(); _ck(self.L.h2w_gl_reduce(self.p, C.byref(a), C.byref(o)), "gl.reduce"); return o
+
+    def _bin(self, fn, name, a, b):
+        o = Assigned(); _ck(fn(self.p, C.byref(a), C.byref(b), C.byref(o)), name); return o
+
+    def add(self, a, b): return self._bin(self.L.h2w_gl_add, "gl.add", a, b)
+    def sub(self, a, b): return self._bin(self.L.h2w_gl_sub, "gl.sub", a, b)
+    def mul(self, a, b): return self._bin(self.L.h2w_gl_mul, "gl.mul", a, b)
+    def div(self, a, b): return self._bin(self.L.h2w_gl_div, "gl.div", a, b)
+
+    def mul_add(self, a, b, c):
+        o = Assigned(); _ck(self.L.h2w_gl_mul_add(self.p, C.byref(a), C.byref(b), C.byref(c), C.byref(o)), "gl.mul_add"); return o
+
+    def inv(self, a):
+        o = Assigned(); _ck(self.L.h2w_gl_inv(self.p, C.byref(a), C.byref(o)), "gl.inv"); return o
+
+
+class Plan:
+    """Shape-compiled batched hot path (h2w_plan_* / h2w_fri_witness_batch)."""
+
+    def __init__(self, shape, consts, device_id=0):
+        self.L = lib()
+        self.shape, self.consts, self.device_id = shape, consts, device_id
+        self.p = self.L.h2w_plan_compile(C.byref(shape), C.byref(consts), device_id)
+        if not self.p:
+            raise H2WError("h2w_plan_compile: " + last_error())
+        self.num_cells = int(self.L.h2w_plan_num_cells(self.p))
+        self.proof_words = int(self.L.h2w_plan_proof_words(self.p))
+        self.num_records = int(self.L.h2w_plan_num_records(self.p))
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.h2w_plan_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace_bytes(self, n):
+        return int(self.L.h2w_plan_workspace_bytes(self.p, n))
+
+    def run(self, proofs_ptr, n, advice_ptr, workspace_ptr, stream=0):
+        _ck(self.L.h2w_fri_witness_batch(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream), "h2w_fri_witness_batch")
+
+    def status(self, workspace_ptr, n, stream=0):
+        st = (C.c_uint32 * n)()
+        _ck(self.L.h2w_plan_status(self.p, workspace_ptr, n, st, stream), "h2w_plan_status")
+        return list(st)
+
+    def last_timing(self):
+        ms = (C.c_float * 3)()
+        _ck(self.L.h2w_plan_last_timing(self.p, ms), "h2w_plan_last_timing")
+        return tuple(ms)

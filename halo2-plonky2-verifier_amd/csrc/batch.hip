@@ -1,0 +1,266 @@
+// batch.hip — API level 3 of include/h2w.h: the batched hot path.
+//
+//   h2w_plan_compile : shape compiler.  Replays the gadget once on the host with a counting sink
+//                      (ValBackend<PlanSink>) to fix the offset of every cell block and strand for this shape.
+//   h2w_fri_witness_batch : per batch, three HIP launches on the caller's stream
+//        k_prologue  one lane per proof      : witness load, Fiat-Shamir challenger (serial sponge), PoW, reduced openings
+//        k_strands   one lane per (proof, query[, merkle tree]) : FRI query glue and Merkle paths (value domain)
+//        expand      one lane per advice cell: the HBM-write-bound materialisation (expand.hip)
+// Data layout in HBM (per batch): proofs [n][proof_words] u64 ; records [n][n_records] 32 B ; challenge blocks [n] ;
+// advice [n][n_cells] 32 B canonical-LE Fr.  Record metas / templates / Poseidon constants are per-shape and shared.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include <cstring>
+#include "common.h"
+#include "valbackend.h"
+
+namespace h2w {
+
+typedef ValBackend<DevSink> DevB;
+typedef ChallengeBlock<DevB> DevCB;
+
+struct PlanSink {
+    std::vector<uint64_t> *meta; const TemplateTable *tt; StrandTable *st;
+    uint64_t nrec = 0, cell_off = 0, cur_q_rec = 0, cur_q_cell = 0, mk_rec0 = 0, mk_cell0 = 0; bool mk_zc = false;
+    void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta->push_back(meta_pack((uint32_t)t, cell_off)); nrec++; cell_off += (uint64_t)tt->ncells(t); }
+    void cell(const fr_t &) { cell_off++; }
+    void skip(uint64_t, uint64_t) {}
+    void merkle_begin(int, int, bool zc) { mk_rec0 = nrec; mk_cell0 = cell_off; mk_zc = zc; }
+    void merkle_end(int q, int kind, bool zc) {
+        if (q > 1) return;
+        st->mk_rec_rel[q][kind] = mk_rec0 - cur_q_rec; st->mk_cell_rel[q][kind] = mk_cell0 - cur_q_cell;
+        st->mk_nrec[q][kind] = nrec - mk_rec0; st->mk_ncell[q][kind] = cell_off - mk_cell0;
+        if (!mk_zc && zc) st->first_zero_kind = (q == 0) ? kind : -2;
+    }
+    void query_begin(int q) { cur_q_rec = nrec; cur_q_cell = cell_off; if (q <= 1) { st->q_rec0[q] = nrec; st->q_cell0[q] = cell_off; } }
+    void query_end(int q) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; } }
+};
+
+struct BatchArgs {
+    h2w_shape_t shape; const h2w_poseidon_consts_t *consts;
+    const uint64_t *proofs; uint64_t proof_words;
+    rec_t *recs; uint64_t rec_stride;
+    fr_t *out; uint64_t cell_stride;
+    DevCB *cbs; uint32_t *status;
+    const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
+    StrandTable st; FrParams P;
+    int nproofs;
+};
+
+__device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
+    ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
+    c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = &A.st; c.split = true;
+    return c;
+}
+
+__global__ __launch_bounds__(64) void k_prologue(BatchArgs A) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.nproofs) return;
+    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells;
+    DevB be(sink, make_cfg(A, p), true);
+    Verifier<DevB> V(be, A.shape, A.consts);
+    V.prologue(A.cbs[p]);
+    A.status[p] = be.status;
+}
+
+// blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
+__global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = A.shape.num_queries;
+    if (idx >= A.nproofs * nq) return;
+    const int p = idx / nq, q = idx % nq, role = blockIdx.y, sq = q == 0 ? 0 : 1;
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;   // initial oracles
+    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells;
+    sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
+    const DevCB &cb = A.cbs[p];
+    if (role == 0) {
+        DevB be(sink, make_cfg(A, p), true);
+        Verifier<DevB> V(be, A.shape, A.consts);
+        V.query_round(q, cb);
+        if (be.status) atomicCAS(&A.status[p], 0u, be.status);
+        return;
+    }
+    const int kind = role <= n_or ? role - 1 : 3 + (role - 1 - n_or);   // roles 1..n_or: initial oracles; then fold steps
+    sink.nrec += A.st.mk_rec_rel[sq][kind]; sink.cell_off += A.st.mk_cell_rel[sq][kind];
+    DevB be(sink, make_cfg(A, p), !(q == 0 && kind == A.st.first_zero_kind));
+    Verifier<DevB> V(be, A.shape, A.consts);
+    // index bits of this strand (fri/mod.rs:363-369, 407-408), from the query-index challenge value
+    const uint64_t x = cb.fri_query_indices[q];
+    const int lde = V.d.lde_bits; int lo = 0;
+    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
+    uint64_t bits[64]; const int nb = lde - lo;
+    for (int i = 0; i < nb; i++) bits[i] = (x >> (lo + i)) & 1;
+    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
+    V.merkle_strand(q, kind, bits, nb, cap_index);
+    if (be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+
+__global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        ulonglong4 c = cells[i]; unsigned long long m = (i + 1) * 0x9E3779B97F4A7C15ULL | 1ULL;
+        a0 += c.x * m; a1 += c.y * (m + 2); a2 += c.z * (m + 4); a3 += c.w * (m + 6);
+    }
+    for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); a2 += __shfl_down(a2, d, 64); a3 += __shfl_down(a3, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out4[0], a0); atomicAdd(&out4[1], a1); atomicAdd(&out4[2], a2); atomicAdd(&out4[3], a3); }
+}
+
+}  // namespace h2w
+
+using namespace h2w;
+
+struct h2w_plan {
+    h2w_shape_t shape; int device;
+    TemplateTable tt; DeviceTables dt; StrandTable st; FrParams P;
+    Derived d; ProofLayout pl;
+    uint64_t nrec = 0, ncells = 0;
+    uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
+    hipEvent_t ev[3]; bool ev_ready = false, ev_recorded = false;
+    explicit h2w_plan(int L) : tt(L) {}
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" {
+
+h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t *consts, int device_id) {
+    if (!shape || !consts) { set_error("h2w_plan_compile: null argument"); return nullptr; }
+    const h2w_shape_t &s = *shape;
+    if (s.lookup_bits < 2 || s.lookup_bits > 28 || s.num_queries < 1 || s.num_queries > MAX_QUERIES || s.cap_height < 0 || (1 << s.cap_height) > MAX_CAP ||
+        s.arity_bits < 1 || (1 << s.arity_bits) > MAX_ARITY || s.n_cols + s.n_perm_z + s.n_quotient > MAX_BATCH_POLYS || s.hash_mode < 0 || s.hash_mode > 1 ||
+        s.degree_bits + s.rate_bits > 63 || s.degree_bits + s.rate_bits < s.cap_height || s.pow_bits < 0 || s.pow_bits > 63) {
+        set_error("h2w_plan_compile: unsupported shape"); return nullptr;
+    }
+    h2w_plan *pl = new h2w_plan(s.lookup_bits);
+    pl->shape = s; pl->device = device_id; pl->P = fr_params_init();
+    pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
+    if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
+    memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1;
+    // host inverse table
+    std::vector<fr_t> inv(2 * INV_TAB, fr_zero());
+    for (int k2 = 1; k2 < INV_TAB; k2++) { inv[k2] = fr_inv(fr_from_u64((uint64_t)k2), pl->P); inv[INV_TAB + k2] = fr_neg(inv[k2]); }
+    // shape compile: sequential replay with the counting sink on an all-zero proof
+    std::vector<uint64_t> meta; std::vector<uint64_t> zero_proof(pl->pl.total, 0);
+    {
+        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st;
+        ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = s.hash_mode; cfg.L = s.lookup_bits; cfg.P = pl->P;
+        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false;
+        ValBackend<PlanSink> be(sink, cfg, false);
+        Verifier<ValBackend<PlanSink>> V(be, pl->shape, consts);
+        ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
+        V.run_all(*cb);
+        delete cb;
+        pl->nrec = sink.nrec; pl->ncells = sink.cell_off;
+        pl->st.pro_nrec = pl->st.q_rec0[0]; pl->st.pro_ncell = pl->st.q_cell0[0]; pl->st.total_rec = sink.nrec; pl->st.total_cell = sink.cell_off;
+        if (s.num_queries == 1) {
+            pl->st.q_rec0[1] = pl->st.q_rec0[0]; pl->st.q_cell0[1] = pl->st.q_cell0[0]; pl->st.q_nrec[1] = pl->st.q_nrec[0]; pl->st.q_ncell[1] = pl->st.q_ncell[0];
+            for (int k2 = 0; k2 < MK_KINDS; k2++) { pl->st.mk_rec_rel[1][k2] = pl->st.mk_rec_rel[0][k2]; pl->st.mk_cell_rel[1][k2] = pl->st.mk_cell_rel[0][k2]; pl->st.mk_nrec[1][k2] = pl->st.mk_nrec[0][k2]; pl->st.mk_ncell[1][k2] = pl->st.mk_ncell[0][k2]; }
+        }
+        if (pl->st.first_zero_kind == -2) { set_error("h2w_plan_compile: internal: first load_zero outside query 0"); delete pl; return nullptr; }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        // no GPU: the plan is still usable for layout queries (cells, records, proof words); batch calls fail.
+        pl->device = -1; return pl;
+    }
+    if (device_id < 0 || device_id >= ndev) { set_error("h2w_plan_compile: device_id out of range"); delete pl; return nullptr; }
+    auto up = [&]() -> int {
+        H2W_HIP(hipSetDevice(device_id));
+        if (pl->dt.upload(pl->tt) != 0) return -1;
+        H2W_HIP(hipMalloc((void **)&pl->d_meta, meta.size() * sizeof(uint64_t)));
+        H2W_HIP(hipMemcpy(pl->d_meta, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t)));
+        H2W_HIP(hipMemcpy(pl->d_consts, consts, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
+        std::vector<uint16_t> nc(T_MAX, 0); for (size_t i = 0; i < pl->tt.info.size(); i++) nc[i] = pl->tt.info[i].ncells;
+        H2W_HIP(hipMalloc((void **)&pl->d_ncells, nc.size() * sizeof(uint16_t)));
+        H2W_HIP(hipMemcpy(pl->d_ncells, nc.data(), nc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        H2W_HIP(hipMalloc((void **)&pl->d_inv, inv.size() * sizeof(fr_t)));
+        H2W_HIP(hipMemcpy(pl->d_inv, inv.data(), inv.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+        for (int i = 0; i < 3; i++) H2W_HIP(hipEventCreate(&pl->ev[i]));
+        pl->ev_ready = true;
+        return 0;
+    };
+    if (up() != 0) { delete pl; return nullptr; }
+    return pl;
+}
+void h2w_plan_free(h2w_plan *p) {
+    if (!p) return;
+    if (p->d_meta) (void)hipFree(p->d_meta);
+    if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->d_ncells) (void)hipFree(p->d_ncells);
+    if (p->d_inv) (void)hipFree(p->d_inv);
+    if (p->ev_ready) for (int i = 0; i < 3; i++) (void)hipEventDestroy(p->ev[i]);
+    p->dt.free();
+    delete p;
+}
+uint64_t h2w_plan_num_cells(const h2w_plan *p) { return p ? p->ncells : 0; }
+uint64_t h2w_plan_proof_words(const h2w_plan *p) { return p ? p->pl.total : 0; }
+uint64_t h2w_plan_num_records(const h2w_plan *p) { return p ? p->nrec : 0; }
+static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_cbs, size_t &o_status, size_t &total) {
+    size_t o = 0;
+    o_recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
+    o_cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
+    o_status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
+    total = o;
+}
+uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
+    if (!p) return 0;
+    size_t a, b, c, t; ws_layout(p, n_proofs, a, b, c, t); return t;
+}
+int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
+    if (!p) { set_error("h2w_fri_witness_batch: null plan"); return -1; }
+    if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
+    if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
+    if (n_proofs == 0) return 0;
+    if (n_proofs * (uint64_t)p->shape.num_queries > 0x7fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t o_recs, o_cbs, o_status, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, total);
+    char *ws = (char *)workspace_dev;
+    BatchArgs A;
+    A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
+    A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = p->ncells;
+    A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
+    A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
+    H2W_HIP(hipEventRecord(p->ev[0], stream));
+    hipLaunchKernelGGL(k_prologue, dim3((unsigned)((n_proofs + 63) / 64)), dim3(64), 0, stream, A);
+    const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
+    // roles: 0 = query glue, then one role per merkle strand kind (initial oracles, fold steps)
+    hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+    H2W_HIP(hipEventRecord(p->ev[1], stream));
+    ExpandArgs E;
+    E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
+    p->dt.fill(E); E.rb = p->tt.rb;
+    int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
+    launch_expand(E, n_proofs, gx, stream);
+    H2W_HIP(hipEventRecord(p->ev[2], stream));
+    p->ev_recorded = true;
+    H2W_HIP(hipGetLastError());
+    return 0;
+}
+int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {
+    if (!p || !workspace_dev || !host_status) { set_error("h2w_plan_status: null argument"); return -1; }
+    size_t o_recs, o_cbs, o_status, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, total);
+    hipStream_t stream = (hipStream_t)stream_;
+    H2W_HIP(hipMemcpyAsync(host_status, (const char *)workspace_dev + o_status, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    H2W_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream_) {
+    if (!advice_dev || !digest4_dev) { set_error("h2w_advice_digest: null argument"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    H2W_HIP(hipMemsetAsync(digest4_dev, 0, 32, stream));
+    if (n_cells) hipLaunchKernelGGL(k_digest, dim3(2048), dim3(256), 0, stream, (const ulonglong4 *)advice_dev, n_cells, (unsigned long long *)digest4_dev);
+    H2W_HIP(hipGetLastError());
+    return 0;
+}
+int h2w_plan_last_timing(h2w_plan *p, float ms[3]) {
+    if (!p || !p->ev_recorded) { set_error("h2w_plan_last_timing: no batch recorded"); return -1; }
+    H2W_HIP(hipEventSynchronize(p->ev[2]));
+    H2W_HIP(hipEventElapsedTime(&ms[0], p->ev[0], p->ev[1]));
+    H2W_HIP(hipEventElapsedTime(&ms[1], p->ev[1], p->ev[2]));
+    H2W_HIP(hipEventElapsedTime(&ms[2], p->ev[0], p->ev[2]));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// common.h — shared host-side plumbing of libh2w (error handling, device tables, kernel launch prototypes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include "records.h"
+
+namespace h2w {
+
+void set_error(const std::string &s);
+extern thread_local std::string g_last_error;
+
+#define H2W_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    h2w::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return -1; } } while (0)
+
+// arguments of the expansion kernel (expand.hip)
+struct ExpandArgs {
+    const uint64_t *meta;      // [nrec] template id << 56 | first cell offset (per proof, shared by the batch)
+    const rec_t *recs;         // [nproofs][rec_stride]
+    uint64_t nrec, rec_stride;
+    fr_t *out;                 // [nproofs][cell_stride]
+    uint64_t cell_stride;
+    const fr_t *pool;          // literal pool (T_LITERAL), may be null
+    const uint32_t *slots; uint32_t nslots;
+    const tmpl_info_t *info; uint32_t ntmpl;
+    const fr_t *consts; uint32_t nconsts;
+    int rb;
+};
+void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
+
+constexpr int MAX_SLOTS = 1536;
+constexpr int MAX_CONSTS = 96;
+
+// device copies of a TemplateTable
+struct DeviceTables {
+    uint32_t *slots = nullptr; tmpl_info_t *info = nullptr; fr_t *consts = nullptr;
+    uint32_t nslots = 0, ntmpl = 0, nconsts = 0;
+    int upload(const TemplateTable &tt) {
+        free();
+        if (tt.slots.size() > MAX_SLOTS || tt.consts.size() > MAX_CONSTS || tt.info.size() > T_MAX) { set_error("template table too large"); return -1; }
+        nslots = (uint32_t)tt.slots.size(); ntmpl = (uint32_t)tt.info.size(); nconsts = (uint32_t)tt.consts.size();
+        H2W_HIP(hipMalloc((void **)&slots, nslots * sizeof(uint32_t)));
+        H2W_HIP(hipMalloc((void **)&info, ntmpl * sizeof(tmpl_info_t)));
+        H2W_HIP(hipMalloc((void **)&consts, (nconsts ? nconsts : 1) * sizeof(fr_t)));
+        H2W_HIP(hipMemcpy(slots, tt.slots.data(), nslots * sizeof(uint32_t), hipMemcpyHostToDevice));
+        H2W_HIP(hipMemcpy(info, tt.info.data(), ntmpl * sizeof(tmpl_info_t), hipMemcpyHostToDevice));
+        if (nconsts) H2W_HIP(hipMemcpy(consts, tt.consts.data(), nconsts * sizeof(fr_t), hipMemcpyHostToDevice));
+        return 0;
+    }
+    void fill(ExpandArgs &A) const { A.slots = slots; A.nslots = nslots; A.info = info; A.ntmpl = ntmpl; A.consts = consts; A.nconsts = nconsts; }
+    void free() {
+        if (slots) hipFree(slots); if (info) hipFree(info); if (consts) hipFree(consts);
+        slots = nullptr; info = nullptr; consts = nullptr;
+    }
+};
+
+}  // namespace h2w

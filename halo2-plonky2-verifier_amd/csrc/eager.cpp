@@ -1,0 +1,366 @@
+// eager.cpp — API levels 1 and 2 of include/h2w.h: the NativeChip-shaped eager context.
+//
+// Mirrors verifier/src/field/native.rs (every method 1:1) and the fused GoldilocksChip ops of
+// verifier/src/field/goldilocks/base.rs.  Values are computed here on the host at call time (the reference
+// reads AssignedValue::value() for its hints); the advice CELLS are not: each call appends a compact 32-byte
+// record (or, for rare wide/irregular templates, literal cells) and the GPU expansion kernel (expand.hip)
+// materialises the stream when the advice is requested.  There is no CPU cell path: without a HIP device
+// h2w_ctx_advice_device / h2w_ctx_download fail.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "records.h"
+#include "common.h"
+
+namespace h2w {
+
+thread_local std::string g_last_error;
+void set_error(const std::string &s) { g_last_error = s; }
+static uint32_t g_next_ctx_id = 1;
+
+}  // namespace h2w
+
+using namespace h2w;
+
+struct h2w_ctx {
+    int L, witness_gen_only, device; uint32_t id;
+    TemplateTable tt; FrParams P;
+    std::vector<uint64_t> meta; std::vector<rec_t> recs; std::vector<fr_t> pool;
+    uint64_t ncells = 0;
+    bool zero_set = false; uint64_t zero_off = 0;
+    int err = 0;
+    std::vector<fr_t> inv_pos, inv_neg;
+    // device side
+    void *d_out = nullptr, *d_meta = nullptr, *d_recs = nullptr, *d_pool = nullptr;
+    DeviceTables dt;
+    bool dt_ready = false; size_t dt_nslots = 0, dt_nconsts = 0, dt_ntmpl = 0;
+    explicit h2w_ctx(int L_) : tt(L_) {}
+};
+
+namespace {
+
+typedef h2w_assigned_t Av;
+inline bool fits64(const fr_t &v) { return (v.l[1] | v.l[2] | v.l[3]) == 0; }
+inline Av mk(h2w_ctx *c, const fr_t &v, uint64_t off) { Av a; a.value = v; a.offset = off; a.ctx_id = c->id; a.has_cell = 1; return a; }
+
+inline void lit(h2w_ctx *c, const fr_t &v) {
+    if (!c->recs.empty() && meta_tmpl(c->meta.back()) == T_LITERAL && c->recs.back().a + c->recs.back().b == c->pool.size() &&
+        meta_off(c->meta.back()) + c->recs.back().b == c->ncells) {
+        c->recs.back().b++;
+    } else {
+        c->meta.push_back(meta_pack(T_LITERAL, c->ncells));
+        c->recs.push_back(rec_t{(uint64_t)c->pool.size(), 1, 0, 0});
+    }
+    c->pool.push_back(v); c->ncells++;
+}
+inline void rec(h2w_ctx *c, int t, uint64_t a, uint64_t b, uint64_t cc, uint64_t d) {
+    c->meta.push_back(meta_pack((uint32_t)t, c->ncells));
+    c->recs.push_back(rec_t{a, b, cc, d});
+    c->ncells += (uint64_t)c->tt.ncells(t);
+}
+inline void cell(h2w_ctx *c, const fr_t &v) { if (fits64(v)) rec(c, T_CONST1, v.l[0], 0, 0, 0); else lit(c, v); }
+inline fr_t fmul(h2w_ctx *c, const fr_t &a, const fr_t &b) { return fr_mul(a, b, c->P); }
+
+fr_t inv_cached(h2w_ctx *c, const fr_t &x) {  // Assigned::Rational(1, x) -> x^{-1}
+    const size_t N = 96;
+    if (c->inv_pos.empty()) {
+        c->inv_pos.resize(N); c->inv_neg.resize(N);
+        for (size_t k = 1; k < N; k++) { c->inv_pos[k] = fr_inv(fr_from_u64(k), c->P); c->inv_neg[k] = fr_neg(c->inv_pos[k]); }
+    }
+    if (fits64(x) && x.l[0] < N) return c->inv_pos[x.l[0]];
+    fr_t nx = fr_neg(x);
+    if (fits64(nx) && nx.l[0] < N) return c->inv_neg[nx.l[0]];
+    return fr_inv(x, c->P);
+}
+
+// ---- halo2-base templates; each returns the value/offset the reference returns
+Av t_gate(h2w_ctx *c, const fr_t &C, const fr_t &A, const fr_t &B) {  // [C, A, B, A*B+C]
+    fr_t v = fr_add(fmul(c, A, B), C);
+    if (fits64(A) && fits64(B) && fits64(C)) rec(c, T_GATE, A.l[0], B.l[0], C.l[0], 0);
+    else { lit(c, C); lit(c, A); lit(c, B); lit(c, v); }
+    return mk(c, v, c->ncells - 1);
+}
+Av t_sub(h2w_ctx *c, const fr_t &a, const fr_t &b) {  // [a-b, b, 1, a] -> cell -4
+    fr_t d = fr_sub(a, b);
+    lit(c, d); lit(c, b); lit(c, fr_from_u64(1)); lit(c, a);
+    return mk(c, d, c->ncells - 4);
+}
+Av t_select(h2w_ctx *c, const fr_t &a, const fr_t &b, const fr_t &sel) {
+    fr_t diff = fr_sub(a, b), out = fr_add(fmul(c, diff, sel), b);
+    lit(c, diff); lit(c, fr_from_u64(1)); lit(c, b); lit(c, a); lit(c, b); lit(c, sel); lit(c, diff); lit(c, out);
+    return mk(c, out, c->ncells - 1);
+}
+Av t_is_zero(h2w_ctx *c, const fr_t &a) {  // [z, a, inv, 1, 0, a, z, 0] -> cell -2
+    bool z = fr_is_zero(a);
+    fr_t zv = fr_from_u64(z ? 1 : 0), inv = z ? fr_from_u64(1) : inv_cached(c, a);
+    lit(c, zv); lit(c, a); lit(c, inv); lit(c, fr_from_u64(1)); lit(c, fr_zero()); lit(c, a); lit(c, zv); lit(c, fr_zero());
+    return mk(c, zv, c->ncells - 2);
+}
+void t_idx_to_indicator(h2w_ctx *c, const fr_t &idx, size_t len, Av *out) {
+    for (size_t i = 0; i < len; i++) {
+        if (i == 0) out[0] = t_is_zero(c, idx);
+        else { Av d = t_sub(c, idx, fr_from_u64(i)); out[i] = t_is_zero(c, d.value); }
+    }
+}
+Av t_select_by_indicator(h2w_ctx *c, const Av *a, size_t stride, const Av *ind, size_t len) {
+    fr_t sum = fr_zero(); lit(c, fr_zero());
+    for (size_t i = 0; i < len; i++) {
+        sum = fr_add(sum, fmul(c, a[i * stride].value, ind[i].value));
+        lit(c, a[i * stride].value); lit(c, ind[i].value); lit(c, sum);
+    }
+    return mk(c, sum, c->ncells - 1);
+}
+// inner_product(a, consts b): returns acc; cell offsets of a[i]: row (i=0, short form) / row+1+3(i-1)
+Av t_inner_product(h2w_ctx *c, const fr_t *a, const fr_t *b, size_t n) {
+    fr_t sum; size_t start = 0;
+    if (n > 0 && fr_eq(b[0], fr_from_u64(1))) { sum = a[0]; lit(c, a[0]); start = 1; }
+    else { sum = fr_zero(); lit(c, fr_zero()); }
+    for (size_t i = start; i < n; i++) { sum = fr_add(sum, fmul(c, a[i], b[i])); lit(c, a[i]); lit(c, b[i]); lit(c, sum); }
+    return mk(c, sum, c->ncells - 1);
+}
+void t_assert_bit(h2w_ctx *c, const fr_t &x) { lit(c, fr_zero()); lit(c, x); lit(c, x); lit(c, x); }
+void t_range_check(h2w_ctx *c, const Av &a, size_t bits) {
+    const int L = c->L;
+    if (bits == 0) return;
+    if (fits64(a.value) && bits <= 64) {   // compact: one record per range check
+        int t = c->tt.rc_template((int)bits);
+        if (t >= 0) { if (c->tt.ncells(t) > 0) rec(c, t, a.value.l[0], 0, 0, 0); return; }
+    }
+    size_t n = (bits + L - 1) / L, rem = bits % L; fr_t last = a.value;
+    if (n > 1) {
+        std::vector<fr_t> limbs(n), bases(n);
+        for (size_t i = 0; i < n; i++) { limbs[i] = fr_from_u64(fr_bits(a.value, (int)(i * L), L)); bases[i] = fr_pow2((int)(i * L)); }
+        t_inner_product(c, limbs.data(), bases.data(), n);
+        last = limbs[n - 1];
+    }
+    if (rem == 1) t_assert_bit(c, last);
+    else if (rem > 1) t_gate(c, fr_zero(), last, fr_pow2((int)(L - rem)));
+}
+int bit_length(uint64_t b) { int n = 0; while (b) { n++; b >>= 1; } return n; }
+void t_check_less_than_safe(h2w_ctx *c, const Av &a, uint64_t b) {
+    const int L = c->L; size_t rb = (size_t)((bit_length(b) + L - 1) / L * L);
+    if (b == GL_P && fits64(a.value)) { rec(c, T_CLT_SAFE, a.value.l[0], 0, 0, 0); return; }
+    t_range_check(c, a, rb);
+    fr_t p2 = fr_pow2((int)rb), sh = fr_add(p2, a.value), bv = fr_from_u64(b), d = fr_sub(sh, bv);
+    uint64_t first = c->ncells;
+    lit(c, d); lit(c, bv); lit(c, fr_from_u64(1)); lit(c, sh); lit(c, fr_neg(p2)); lit(c, fr_from_u64(1)); lit(c, a.value);
+    t_range_check(c, mk(c, d, first), rb);
+}
+
+bool check(h2w_ctx *c, const char *fn) {
+    if (!c) { set_error(std::string(fn) + ": null context"); return false; }
+    return true;
+}
+int fail(h2w_ctx *c, const std::string &msg) { if (c) c->err = 1; set_error(msg); return -1; }
+
+}  // namespace
+
+extern "C" {
+
+int h2w_abi_version(void) { return H2W_ABI_VERSION; }
+const char *h2w_last_error(void) { return g_last_error.c_str(); }
+int h2w_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id) {
+    if (lookup_bits < 2 || lookup_bits > 28) { set_error("h2w_ctx_new: lookup_bits out of range [2,28]"); return nullptr; }
+    h2w_ctx *c = new h2w_ctx(lookup_bits);
+    c->L = lookup_bits; c->witness_gen_only = witness_gen_only; c->device = device_id; c->id = g_next_ctx_id++;
+    c->P = fr_params_init();
+    return c;
+}
+void h2w_ctx_free(h2w_ctx *c) {
+    if (!c) return;
+    if (c->d_out) hipFree(c->d_out);
+    if (c->d_meta) hipFree(c->d_meta);
+    if (c->d_recs) hipFree(c->d_recs);
+    if (c->d_pool) hipFree(c->d_pool);
+    c->dt.free();
+    delete c;
+}
+uint64_t h2w_num_cells(const h2w_ctx *c) { return c ? c->ncells : 0; }
+int h2w_ctx_error(const h2w_ctx *c) { return c ? c->err : 1; }
+
+int h2w_load_constant(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_constant")) return -1; cell(c, *v); *out = mk(c, *v, c->ncells - 1); return 0; }
+int h2w_load_witness(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_witness")) return -1; cell(c, *v); *out = mk(c, *v, c->ncells - 1); return 0; }
+int h2w_load_zero(h2w_ctx *c, h2w_assigned_t *out) {
+    if (!check(c, "h2w_load_zero")) return -1;
+    if (!c->zero_set) { cell(c, fr_zero()); c->zero_set = true; c->zero_off = c->ncells - 1; }
+    *out = mk(c, fr_zero(), c->zero_off); return 0;
+}
+int h2w_load_constants(h2w_ctx *c, const h2w_fr_t *v, size_t n, h2w_assigned_t *out) {
+    if (!check(c, "h2w_load_constants")) return -1;
+    for (size_t i = 0; i < n; i++) { cell(c, v[i]); out[i] = mk(c, v[i], c->ncells - 1); }
+    return 0;
+}
+int h2w_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
+    if (!check(c, "h2w_add")) return -1;
+    *out = t_gate(c, a->value, b->value, fr_from_u64(1)); return 0;      // [a, b, 1, a+b]
+}
+int h2w_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
+    if (!check(c, "h2w_mul")) return -1;
+    *out = t_gate(c, fr_zero(), a->value, b->value); return 0;          // [0, a, b, a*b]
+}
+int h2w_mul_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
+    if (!check(c, "h2w_mul_add")) return -1;
+    *out = t_gate(c, cc->value, a->value, b->value); return 0;          // [c, a, b, a*b+c]
+}
+int h2w_select(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *sel, h2w_assigned_t *out) {
+    if (!check(c, "h2w_select")) return -1;
+    *out = t_select(c, a->value, b->value, sel->value); return 0;
+}
+int h2w_idx_to_indicator(h2w_ctx *c, const h2w_assigned_t *idx, size_t len, h2w_assigned_t *out) {
+    if (!check(c, "h2w_idx_to_indicator")) return -1;
+    t_idx_to_indicator(c, idx->value, len, out); return 0;
+}
+int h2w_select_from_idx(h2w_ctx *c, const h2w_assigned_t *arr, size_t n, const h2w_assigned_t *idx, h2w_assigned_t *out) {
+    if (!check(c, "h2w_select_from_idx")) return -1;
+    std::vector<Av> ind(n);
+    t_idx_to_indicator(c, idx->value, n, ind.data());
+    *out = t_select_by_indicator(c, arr, 1, ind.data(), n); return 0;
+}
+int h2w_select_array_by_indicator(h2w_ctx *c, const h2w_assigned_t *arr2d, size_t len, size_t w, const h2w_assigned_t *ind, h2w_assigned_t *out) {
+    if (!check(c, "h2w_select_array_by_indicator")) return -1;
+    for (size_t j = 0; j < w; j++) out[j] = t_select_by_indicator(c, arr2d + j, w, ind, len);
+    return 0;
+}
+int h2w_num_to_bits(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits, h2w_assigned_t *out) {
+    if (!check(c, "h2w_num_to_bits")) return -1;
+    if (range_bits == 0 || range_bits > 253) return fail(c, "h2w_num_to_bits: range_bits out of range");
+    std::vector<fr_t> bits(range_bits), bases(range_bits);
+    for (size_t i = 0; i < range_bits; i++) { bits[i] = fr_from_u64(fr_bits(a->value, (int)i, 1)); bases[i] = fr_pow2((int)i); }
+    uint64_t row = c->ncells;
+    t_inner_product(c, bits.data(), bases.data(), range_bits);
+    out[0] = mk(c, bits[0], row);
+    for (size_t i = 1; i < range_bits; i++) out[i] = mk(c, bits[i], row + 1 + 3 * (i - 1));
+    for (size_t i = 0; i < range_bits; i++) t_assert_bit(c, bits[i]);
+    return 0;
+}
+int h2w_bits_to_num(h2w_ctx *c, const h2w_assigned_t *bits, size_t n, h2w_assigned_t *out) {
+    if (!check(c, "h2w_bits_to_num")) return -1;
+    std::vector<fr_t> a(n), b(n);
+    for (size_t i = 0; i < n; i++) { a[i] = bits[i].value; b[i] = fr_pow2((int)i); }
+    *out = t_inner_product(c, a.data(), b.data(), n); return 0;
+}
+int h2w_decompose_le(h2w_ctx *c, const h2w_assigned_t *num, size_t limb_bits, size_t num_limbs, h2w_assigned_t *out) {
+    if (!check(c, "h2w_decompose_le")) return -1;
+    if (limb_bits == 0 || limb_bits > 64) return fail(c, "h2w_decompose_le: limb_bits out of range");
+    std::vector<fr_t> limbs(num_limbs), bases(num_limbs);
+    for (size_t i = 0; i < num_limbs; i++) { limbs[i] = fr_from_u64(fr_bits(num->value, (int)(i * limb_bits), (int)limb_bits)); bases[i] = fr_pow2((int)(i * limb_bits)); }
+    uint64_t row = c->ncells;
+    t_inner_product(c, limbs.data(), bases.data(), num_limbs);
+    out[0] = mk(c, limbs[0], row);
+    for (size_t i = 0; i + 1 < num_limbs; i++) out[i + 1] = mk(c, limbs[i + 1], row + 1 + 3 * i);
+    for (size_t i = 0; i < num_limbs; i++) t_range_check(c, out[i], limb_bits);
+    return 0;
+}
+int h2w_limbs_to_num(h2w_ctx *c, const h2w_assigned_t *limbs, size_t n, size_t limb_bits, h2w_assigned_t *out) {
+    if (!check(c, "h2w_limbs_to_num")) return -1;
+    std::vector<fr_t> a(n), b(n);
+    for (size_t i = 0; i < n; i++) { a[i] = limbs[i].value; b[i] = fr_pow2((int)(i * limb_bits)); }
+    *out = t_inner_product(c, a.data(), b.data(), n); return 0;
+}
+int h2w_check_less_than_safe(h2w_ctx *c, const h2w_assigned_t *a, uint64_t b) { if (!check(c, "h2w_check_less_than_safe")) return -1; t_check_less_than_safe(c, *a, b); return 0; }
+int h2w_range_check(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits) { if (!check(c, "h2w_range_check")) return -1; t_range_check(c, *a, range_bits); return 0; }
+int h2w_constrain_equal(h2w_ctx *c, const h2w_assigned_t *, const h2w_assigned_t *) { return check(c, "h2w_constrain_equal") ? 0 : -1; }
+
+// ---------------------------------------------------------------- fused Goldilocks level (field/goldilocks/base.rs)
+static inline bool gl_canon(const fr_t &v) { return fits64(v) && v.l[0] < GL_P; }
+int h2w_gl_load_constant(h2w_ctx *c, uint64_t a, h2w_assigned_t *out) { fr_t v = fr_from_u64(a); return h2w_load_constant(c, &v, out); }
+int h2w_gl_load_witness(h2w_ctx *c, uint64_t a, h2w_assigned_t *out) {
+    if (!check(c, "h2w_gl_load_witness")) return -1;
+    uint64_t off = c->ncells; rec(c, T_LOADW, a, 0, 0, 0);
+    *out = mk(c, fr_from_u64(a), off); return 0;
+}
+// record for the 61-cell reduce tail of an arbitrary (< 2^128) value; returns remainder wire
+static int gl_reduce_impl(h2w_ctx *c, const fr_t &v, h2w_assigned_t *out) {
+    if (v.l[2] | v.l[3]) return fail(c, "h2w_gl_reduce: value >= 2^128 (reference only supports up to p*(p-1), base.rs:345)");
+    u128 V = ((u128)v.l[1] << 64) | v.l[0];
+    uint64_t r = gl_reduce128(V);
+    uint64_t off = c->ncells; rec(c, T_REDUCE, v.l[0], v.l[1], 0, 0);
+    int nl = c->tt.ncells(T_LOADW);
+    *out = mk(c, fr_from_u64(r), off + (uint64_t)nl);    // remainder = second load_witness cell
+    return 0;
+}
+int h2w_gl_reduce(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) { if (!check(c, "h2w_gl_reduce")) return -1; return gl_reduce_impl(c, a->value, out); }
+static int glop(h2w_ctx *c, int t, uint64_t A, uint64_t B, uint64_t C, h2w_assigned_t *out) {
+    uint64_t r = gl_reduce128((u128)A * B + C);
+    uint64_t off = c->ncells; rec(c, t, A, B, C, 0);
+    int pre = (t == T_GLOP) ? 0 : 1, nl = c->tt.ncells(T_LOADW);
+    *out = mk(c, fr_from_u64(r), off + (uint64_t)(pre + 4 + nl));
+    return 0;
+}
+#define GL_ARGS2(fn) if (!check(c, fn)) return -1; if (!fits64(a->value) || !fits64(b->value)) return fail(c, std::string(fn) + ": operand is not a 64-bit Goldilocks wire")
+int h2w_gl_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_add"); return glop(c, T_GLOP, b->value.l[0], 1, a->value.l[0], out); }
+int h2w_gl_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_mul"); return glop(c, T_GLOP, a->value.l[0], b->value.l[0], 0, out); }
+int h2w_gl_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_sub"); return glop(c, T_KB_GLOP, b->value.l[0], GL_NEG_ONE, a->value.l[0], out); }
+int h2w_gl_mul_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
+    GL_ARGS2("h2w_gl_mul_add"); if (!fits64(cc->value)) return fail(c, "h2w_gl_mul_add: operand is not a 64-bit Goldilocks wire");
+    return glop(c, T_GLOP, a->value.l[0], b->value.l[0], cc->value.l[0], out);
+}
+int h2w_gl_div(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
+    GL_ARGS2("h2w_gl_div");
+    if (!gl_canon(a->value) || !gl_canon(b->value)) return fail(c, "h2w_gl_div: non-canonical Goldilocks wire");
+    if (b->value.l[0] == 0) return fail(c, "h2w_gl_div: division by zero (reference asserts, base.rs:379)");
+    uint64_t res = gl_mul(a->value.l[0], gl_inv(b->value.l[0]));
+    h2w_assigned_t rw, prod;
+    h2w_gl_load_witness(c, res, &rw);
+    glop(c, T_GLOP, b->value.l[0], res, 0, &prod);
+    *out = rw; return 0;
+}
+int h2w_gl_inv(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) {
+    if (!check(c, "h2w_gl_inv")) return -1;
+    h2w_assigned_t one; h2w_gl_load_constant(c, 1, &one);
+    return h2w_gl_div(c, &one, a, out);
+}
+
+// ---------------------------------------------------------------- advice hand-off: GPU expansion
+static int ensure_expanded(h2w_ctx *c) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, "h2w: no HIP device visible — the advice stream is only produced on the GPU (no CPU fallback)");
+    if (c->device >= ndev) return fail(c, "h2w: device_id out of range");
+    H2W_HIP(hipSetDevice(c->device));
+    if (c->d_out) { hipFree(c->d_out); c->d_out = nullptr; }
+    if (c->d_meta) { hipFree(c->d_meta); c->d_meta = nullptr; }
+    if (c->d_recs) { hipFree(c->d_recs); c->d_recs = nullptr; }
+    if (c->d_pool) { hipFree(c->d_pool); c->d_pool = nullptr; }
+    if (c->ncells == 0) return 0;
+    if (!c->dt_ready || c->dt_nslots != c->tt.slots.size() || c->dt_nconsts != c->tt.consts.size() || c->dt_ntmpl != c->tt.info.size()) {
+        if (c->dt.upload(c->tt) != 0) return fail(c, "h2w: template upload failed: " + g_last_error);
+        c->dt_ready = true; c->dt_nslots = c->tt.slots.size(); c->dt_nconsts = c->tt.consts.size(); c->dt_ntmpl = c->tt.info.size();
+    }
+    size_t nrec = c->recs.size();
+    H2W_HIP(hipMalloc(&c->d_out, c->ncells * sizeof(fr_t)));
+    H2W_HIP(hipMalloc(&c->d_meta, nrec * sizeof(uint64_t)));
+    H2W_HIP(hipMalloc(&c->d_recs, nrec * sizeof(rec_t)));
+    H2W_HIP(hipMemcpy(c->d_meta, c->meta.data(), nrec * sizeof(uint64_t), hipMemcpyHostToDevice));
+    H2W_HIP(hipMemcpy(c->d_recs, c->recs.data(), nrec * sizeof(rec_t), hipMemcpyHostToDevice));
+    if (!c->pool.empty()) {
+        H2W_HIP(hipMalloc(&c->d_pool, c->pool.size() * sizeof(fr_t)));
+        H2W_HIP(hipMemcpy(c->d_pool, c->pool.data(), c->pool.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+    }
+    ExpandArgs A;
+    A.meta = (const uint64_t *)c->d_meta; A.recs = (const rec_t *)c->d_recs; A.nrec = nrec; A.rec_stride = nrec;
+    A.out = (fr_t *)c->d_out; A.cell_stride = c->ncells; A.pool = (const fr_t *)c->d_pool;
+    c->dt.fill(A); A.rb = c->tt.rb;
+    launch_expand(A, 1, 2048, nullptr);
+    H2W_HIP(hipGetLastError());
+    H2W_HIP(hipDeviceSynchronize());
+    return 0;
+}
+int h2w_ctx_advice_device(h2w_ctx *c, void **dev_ptr) {
+    if (!check(c, "h2w_ctx_advice_device")) return -1;
+    if (ensure_expanded(c) != 0) return -1;
+    *dev_ptr = c->d_out; return 0;
+}
+int h2w_ctx_download(h2w_ctx *c, uint64_t first, uint64_t count, h2w_fr_t *host_dst) {
+    if (!check(c, "h2w_ctx_download")) return -1;
+    if (first + count > c->ncells) return fail(c, "h2w_ctx_download: range out of bounds");
+    if (ensure_expanded(c) != 0) return -1;
+    if (count == 0) return 0;
+    H2W_HIP(hipMemcpy(host_dst, (const fr_t *)c->d_out + first, count * sizeof(fr_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

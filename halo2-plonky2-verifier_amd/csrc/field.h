@@ -1,0 +1,182 @@
+// field.h — Goldilocks (u64) and BN254 Fr (4x64) arithmetic, host + device (gfx950).
+//
+// Goldilocks p = 2^64 - 2^32 + 1 (plonky2 GoldilocksField).  BN254 Fr per SURVEY App. A.
+// Wide-integer work only: 64-bit integer MADs (v_mad_u64_u32 chains), no MFMA.
+#pragma once
+#include <stdint.h>
+#include "../../include/h2w.h"
+
+#if defined(__HIPCC__)
+#define HD __host__ __device__ __forceinline__
+#define HDN __host__ __device__
+#define HF __host__ __device__ inline
+#define HNI __host__ __device__ __attribute__((noinline))
+#else
+#define HD inline
+#define HDN
+#define HF inline
+#define HNI __attribute__((noinline))
+#endif
+
+namespace h2w {
+
+typedef unsigned __int128 u128;
+typedef h2w_fr_t fr_t;
+
+constexpr uint64_t GL_P = 0xFFFFFFFF00000001ULL;
+constexpr uint64_t GL_EPS = 0xFFFFFFFFULL;       // 2^64 mod p = 2^32 - 1
+constexpr uint64_t GL_NEG_ONE = GL_P - 1;
+
+// ---------------------------------------------------------------- Goldilocks
+// x (u128) mod p using 2^64 = 2^32 - 1, 2^96 = -1 (mod p)
+HD uint64_t gl_reduce128(u128 x) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hh = hi >> 32, hl = hi & GL_EPS;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS;                     // borrow: subtract 2^64 = eps (mod p) -> add p... (wraps) 
+    uint64_t t1 = hl * GL_EPS;                     // < 2^64
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;                       // carry: 2^64 = eps
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
+HD uint64_t gl_add(uint64_t a, uint64_t b) { return gl_reduce128((u128)a + b); }
+HD uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
+HD uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce128((u128)a * b); }
+HD uint64_t gl_muladd(uint64_t a, uint64_t b, uint64_t c) { return gl_reduce128((u128)a * b + c); }
+HD uint64_t gl_exp(uint64_t a, uint64_t e) {
+    uint64_t acc = 1;
+    while (e) { if (e & 1) acc = gl_mul(acc, a); a = gl_mul(a, a); e >>= 1; }
+    return acc;
+}
+HD uint64_t gl_inv(uint64_t a) { return gl_exp(a, GL_P - 2); }
+// exact quotient of v by p when v = A*B + C with A,B,C canonical (q < p < 2^64):
+// q = (lo64(v) - r) * p^{-1} mod 2^64, p^{-1} = 1 + 2^32 (mod 2^64)
+HD void gl_divmod128(u128 v, uint64_t &q, uint64_t &r) {
+    r = gl_reduce128(v);
+    uint64_t d = (uint64_t)v - r;
+    q = d + (d << 32);
+}
+// plonky2: MULTIPLICATIVE_GROUP_GENERATOR = 7, TWO_ADICITY = 32, POWER_OF_TWO_GENERATOR = 7^((p-1)/2^32)
+HD uint64_t gl_primitive_root_of_unity(int n_log) {
+    uint64_t g = gl_exp(7, (GL_P - 1) >> 32);
+    for (int i = 0; i < 32 - n_log; i++) g = gl_mul(g, g);
+    return g;
+}
+struct gle_t { uint64_t c[2]; };
+HD gle_t gle_mul(gle_t a, gle_t b) {
+    gle_t r;
+    r.c[0] = gl_add(gl_mul(a.c[0], b.c[0]), gl_mul(7, gl_mul(a.c[1], b.c[1])));
+    r.c[1] = gl_add(gl_mul(a.c[0], b.c[1]), gl_mul(a.c[1], b.c[0]));
+    return r;
+}
+HD gle_t gle_inv(gle_t a) {
+    uint64_t n = gl_sub(gl_mul(a.c[0], a.c[0]), gl_mul(7, gl_mul(a.c[1], a.c[1])));
+    uint64_t ni = gl_inv(n);
+    gle_t r; r.c[0] = gl_mul(a.c[0], ni); r.c[1] = gl_mul(gl_sub(0, a.c[1]), ni);
+    return r;
+}
+
+// ---------------------------------------------------------------- BN254 Fr
+// r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+#define H2W_FR_M0 0x43e1f593f0000001ULL
+#define H2W_FR_M1 0x2833e84879b97091ULL
+#define H2W_FR_M2 0xb85045b68181585dULL
+#define H2W_FR_M3 0x30644e72e131a029ULL
+HD uint64_t fr_mod_limb(int i) { return i == 0 ? H2W_FR_M0 : i == 1 ? H2W_FR_M1 : i == 2 ? H2W_FR_M2 : H2W_FR_M3; }
+
+struct FrParams { fr_t r2; uint64_t ninv; };   // 2^512 mod r, -r^{-1} mod 2^64 (derived at init, never typed)
+
+HD fr_t fr_zero() { fr_t z; z.l[0] = z.l[1] = z.l[2] = z.l[3] = 0; return z; }
+HD fr_t fr_from_u64(uint64_t x) { fr_t z; z.l[0] = x; z.l[1] = z.l[2] = z.l[3] = 0; return z; }
+HD fr_t fr_from_u128(u128 x) { fr_t z; z.l[0] = (uint64_t)x; z.l[1] = (uint64_t)(x >> 64); z.l[2] = z.l[3] = 0; return z; }
+HD bool fr_is_zero(const fr_t &a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+HD bool fr_eq(const fr_t &a, const fr_t &b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+HD bool fr_geq_mod(const fr_t &a) {
+    if (a.l[3] != H2W_FR_M3) return a.l[3] > H2W_FR_M3;
+    if (a.l[2] != H2W_FR_M2) return a.l[2] > H2W_FR_M2;
+    if (a.l[1] != H2W_FR_M1) return a.l[1] > H2W_FR_M1;
+    return a.l[0] >= H2W_FR_M0;
+}
+HD fr_t fr_sub_mod_raw(const fr_t &a) {  // a - r
+    fr_t r; u128 t; uint64_t bw = 0;
+    t = (u128)a.l[0] - H2W_FR_M0 - bw; r.l[0] = (uint64_t)t; bw = (uint64_t)(t >> 64) & 1;
+    t = (u128)a.l[1] - H2W_FR_M1 - bw; r.l[1] = (uint64_t)t; bw = (uint64_t)(t >> 64) & 1;
+    t = (u128)a.l[2] - H2W_FR_M2 - bw; r.l[2] = (uint64_t)t; bw = (uint64_t)(t >> 64) & 1;
+    t = (u128)a.l[3] - H2W_FR_M3 - bw; r.l[3] = (uint64_t)t;
+    return r;
+}
+HD fr_t fr_add(const fr_t &a, const fr_t &b) {
+    fr_t r; u128 t; uint64_t c = 0;
+    for (int i = 0; i < 4; i++) { t = (u128)a.l[i] + b.l[i] + c; r.l[i] = (uint64_t)t; c = (uint64_t)(t >> 64); }
+    if (fr_geq_mod(r)) r = fr_sub_mod_raw(r);
+    return r;
+}
+HD fr_t fr_sub(const fr_t &a, const fr_t &b) {
+    fr_t r; u128 t; uint64_t bw = 0;
+    for (int i = 0; i < 4; i++) { t = (u128)a.l[i] - b.l[i] - bw; r.l[i] = (uint64_t)t; bw = (uint64_t)(t >> 64) & 1; }
+    if (bw) { uint64_t c = 0; for (int i = 0; i < 4; i++) { t = (u128)r.l[i] + fr_mod_limb(i) + c; r.l[i] = (uint64_t)t; c = (uint64_t)(t >> 64); } }
+    return r;
+}
+HD fr_t fr_neg(const fr_t &a) { return fr_sub(fr_zero(), a); }
+// Montgomery product a*b*2^-256 mod r (CIOS, 64-bit limbs -> v_mad_u64_u32 chains on gfx950)
+HNI inline fr_t fr_mont_mul(const fr_t &a, const fr_t &b, uint64_t ninv) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 4; i++) {
+        uint64_t bi = b.l[i]; u128 s; uint64_t c;
+        s = (u128)a.l[0] * bi + t0; t0 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)a.l[1] * bi + t1 + c; t1 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)a.l[2] * bi + t2 + c; t2 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)a.l[3] * bi + t3 + c; t3 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)t4 + c; t4 = (uint64_t)s; t5 = (uint64_t)(s >> 64);
+        uint64_t m = t0 * ninv;
+        s = (u128)m * H2W_FR_M0 + t0; c = (uint64_t)(s >> 64);
+        s = (u128)m * H2W_FR_M1 + t1 + c; t0 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)m * H2W_FR_M2 + t2 + c; t1 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)m * H2W_FR_M3 + t3 + c; t2 = (uint64_t)s; c = (uint64_t)(s >> 64);
+        s = (u128)t4 + c; t3 = (uint64_t)s; t4 = t5 + (uint64_t)(s >> 64);
+    }
+    fr_t r; r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3;
+    if (t4 || fr_geq_mod(r)) r = fr_sub_mod_raw(r);
+    return r;
+}
+// canonical a*b mod r (two Montgomery products)
+HD fr_t fr_mul(const fr_t &a, const fr_t &b, const FrParams &P) {
+    if ((a.l[1] | a.l[2] | a.l[3] | b.l[1] | b.l[2] | b.l[3]) == 0) return fr_from_u128((u128)a.l[0] * b.l[0]);
+    fr_t t = fr_mont_mul(a, b, P.ninv);
+    return fr_mont_mul(t, P.r2, P.ninv);
+}
+inline FrParams fr_params_init() {
+    FrParams P; uint64_t inv = 1;
+    for (int i = 0; i < 6; i++) inv *= 2 - H2W_FR_M0 * inv;
+    P.ninv = (uint64_t)0 - inv;
+    fr_t x = fr_from_u64(1);
+    for (int i = 0; i < 512; i++) x = fr_add(x, x);
+    P.r2 = x;
+    return P;
+}
+HDN inline fr_t fr_pow(const fr_t &a, const fr_t &e, const FrParams &P) {
+    fr_t acc = fr_from_u64(1), base = a;
+    for (int i = 0; i < 256; i++) {
+        if ((e.l[i >> 6] >> (i & 63)) & 1) acc = fr_mul(acc, base, P);
+        base = fr_mul(base, base, P);
+    }
+    return acc;
+}
+HDN inline fr_t fr_inv(const fr_t &a, const FrParams &P) {
+    fr_t e; e.l[0] = H2W_FR_M0 - 2; e.l[1] = H2W_FR_M1; e.l[2] = H2W_FR_M2; e.l[3] = H2W_FR_M3;
+    return fr_pow(a, e, P);
+}
+HD fr_t fr_pow2(int k) { fr_t r = fr_zero(); r.l[k >> 6] = 1ULL << (k & 63); return r; }
+HD uint64_t fr_bits(const fr_t &v, int lo, int width) {
+    if (lo >= 256) return 0;
+    int w = lo >> 6, sh = lo & 63;
+    uint64_t out = v.l[w] >> sh;
+    if (sh && w + 1 < 4) out |= v.l[w + 1] << (64 - sh);
+    return width >= 64 ? out : out & ((1ULL << width) - 1);
+}
+
+}  // namespace h2w

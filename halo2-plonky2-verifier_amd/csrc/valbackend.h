@@ -1,0 +1,195 @@
+// valbackend.h — the value backend: stands in for NativeChip + halo2-base under chips.h / verifier.h.
+//
+// Wires ARE values here (Goldilocks wire = u64, native wire = canonical Fr, bool wire = 0/1): copy constraints
+// are not part of the advice stream.  Every op computes its result natively (Goldilocks mul/reduce on 64-bit
+// integer MADs, Montgomery Fr) and hands the *cells* to a Sink either as a 32-byte block record (the big
+// Goldilocks templates, expanded later by expand.hip) or as direct cells (small irregular templates and BN254
+// Poseidon).  Sinks: DevSink (device memory) and PlanSink (host, counts + metas = the shape compiler).
+// Cell templates: SURVEY.md Appendix A; reduce block: field/goldilocks/base.rs:346-368.
+#pragma once
+#include "records.h"
+#include "verifier.h"
+
+namespace h2w {
+
+constexpr int INV_TAB = 96;
+
+struct StrandTable {
+    // index 0: query 0, index 1: any query >= 1 (they differ by the one cached load_zero cell)
+    uint64_t q_rec0[2], q_cell0[2], q_nrec[2], q_ncell[2];
+    uint64_t mk_rec_rel[2][MK_KINDS], mk_cell_rel[2][MK_KINDS], mk_nrec[2][MK_KINDS], mk_ncell[2][MK_KINDS];
+    int first_zero_kind;     // merkle kind (of query 0) that emits the Context's first load_zero cell; -1 = none
+    uint64_t pro_nrec, pro_ncell, total_rec, total_cell;
+};
+HF uint64_t strand_q_rec(const StrandTable &t, int q) { return q == 0 ? t.q_rec0[0] : t.q_rec0[1] + (uint64_t)(q - 1) * t.q_nrec[1]; }
+HF uint64_t strand_q_cell(const StrandTable &t, int q) { return q == 0 ? t.q_cell0[0] : t.q_cell0[1] + (uint64_t)(q - 1) * t.q_ncell[1]; }
+
+struct ValCfg {
+    const uint64_t *proof;           // this proof's flat words
+    int mode, L;                     // hash mode, lookup bits
+    FrParams P;
+    const fr_t *inv_pos, *inv_neg;   // inverses of +-k, k < INV_TAB (Assigned::Rational(1,x) cells of is_zero)
+    const StrandTable *st;           // null on the sequential (plan) run
+    bool split;                      // true: merkle calls are skipped (their cells belong to merkle strands)
+};
+
+template <class Sink> struct ValBackend {
+    typedef uint64_t Gl; typedef uint64_t Bool; typedef fr_t Fr; typedef u128 Big;
+    Sink &sink; ValCfg cfg; bool zero_cached; uint32_t status;
+    HF ValBackend(Sink &s, const ValCfg &c, bool zero_cached_) : sink(s), cfg(c), zero_cached(zero_cached_), status(0) {}
+
+    HF void fail(uint32_t code) { if (!status) status = code; }
+    HF Gl gl_lit(uint64_t v) { return v; }
+    HF uint64_t gl_val(Gl w) { return w; }
+    HF Gl bool_as_gl(Bool b) { return b; }
+    HF void cell(const fr_t &v) { sink.cell(v); }
+    HF void cell64(uint64_t v) { sink.cell(fr_from_u64(v)); }
+
+    // ---------------------------------------------------------------- Goldilocks block records
+    HF Gl gl_const(uint64_t k) { sink.rec(T_CONST1, k, 0, 0, 0); return k; }
+    HF void gl_const_run(uint64_t k, int n, Gl *out) {
+        if (n == 12) sink.rec(T_REP12, k, 0, 0, 0);
+        else if (n == 4) sink.rec(T_CONST4, k, k, k, k);
+        else for (int i = 0; i < n; i++) sink.rec(T_CONST1, k, 0, 0, 0);
+        for (int i = 0; i < n; i++) out[i] = k;
+    }
+    HF void gl_const4(const uint64_t *w, Gl *out) { sink.rec(T_CONST4, w[0], w[1], w[2], w[3]); for (int i = 0; i < 4; i++) out[i] = w[i]; }
+    HF Gl gl_witness(uint64_t v) { sink.rec(T_LOADW, v, 0, 0, 0); return v; }
+    HF void gl_witness2(uint64_t a, uint64_t b, Gl *out) { sink.rec(T_LOADW2, a, b, 0, 0); out[0] = a; out[1] = b; }
+    HNI Gl glop(int pre, Gl A, Gl B, Gl C) {
+        sink.rec(pre == PRE_NONE ? T_GLOP : pre == PRE_A ? T_KA_GLOP : T_KB_GLOP, A, B, C, 0);
+        return gl_reduce128((u128)A * B + C);
+    }
+    HF Big gl_gate(int pre, Gl A, Gl B, Gl C) { sink.rec(pre == PRE_B ? T_KB_GATE : T_GATE, A, B, C, 0); return (u128)A * B + C; }
+    HF Gl gl_reduce(Big v) { sink.rec(T_REDUCE, (uint64_t)v, (uint64_t)(v >> 64), 0, 0); return gl_reduce128(v); }
+
+    // ---------------------------------------------------------------- small native templates: direct cells
+    HF fr_t inv_small(const fr_t &x) {
+        if ((x.l[1] | x.l[2] | x.l[3]) == 0 && x.l[0] < (uint64_t)INV_TAB) return cfg.inv_pos[x.l[0]];
+        fr_t nx = fr_neg(x);
+        if ((nx.l[1] | nx.l[2] | nx.l[3]) == 0 && nx.l[0] < (uint64_t)INV_TAB) return cfg.inv_neg[nx.l[0]];
+        return fr_inv(x, cfg.P);
+    }
+    HNI Gl select(Gl a, Gl b, Bool sel) {      // [a-b, 1, b, a, b, sel, a-b, out]
+        fr_t diff = fr_sub(fr_from_u64(a), fr_from_u64(b)); Gl out = sel ? a : b;
+        cell(diff); cell64(1); cell64(b); cell64(a); cell64(b); cell64(sel); cell(diff); cell64(out);
+        return out;
+    }
+    HF Bool is_zero_cells(const fr_t &a) {    // [z, a, inv, 1, 0, a, z, 0]
+        bool z = fr_is_zero(a); fr_t inv = z ? fr_from_u64(1) : inv_small(a);
+        cell64(z ? 1 : 0); cell(a); cell(inv); cell64(1); cell64(0); cell(a); cell64(z ? 1 : 0); cell64(0);
+        return z ? 1 : 0;
+    }
+    HNI void idx_to_indicator(Gl idx, int len, Bool *out) {
+        fr_t iv = fr_from_u64(idx);
+        for (int i = 0; i < len; i++) {
+            if (i == 0) out[0] = is_zero_cells(iv);
+            else { fr_t d = fr_sub(iv, fr_from_u64((uint64_t)i)); cell(d); cell64((uint64_t)i); cell64(1); cell(iv); out[i] = is_zero_cells(d); }
+        }
+    }
+    HNI Gl select_by_indicator(const Gl *a, int stride, const Bool *ind, int len) {   // [0, a0, ind0, s0, ...]
+        u128 sum = 0; cell64(0);
+        for (int i = 0; i < len; i++) { sum += (u128)a[i * stride] * ind[i]; cell64(a[i * stride]); cell64(ind[i]); sink.cell(fr_from_u128(sum)); }
+        return (uint64_t)sum;
+    }
+    HNI void num_to_bits(Gl a, int nbits, Bool *out) {     // inner_product(bits, 2^i) then assert_bit per bit
+        for (int i = 0; i < nbits; i++) out[i] = i < 64 ? (a >> i) & 1 : 0;
+        cell64(out[0]);
+        for (int i = 1; i < nbits; i++) { cell64(out[i]); sink.cell(fr_pow2(i)); cell64(i >= 63 ? a : (a & ((2ull << i) - 1))); }
+        for (int i = 0; i < nbits; i++) { cell64(0); cell64(out[i]); cell64(out[i]); cell64(out[i]); }
+    }
+    HF Gl bits_to_num(const Bool *bits, int n) {          // inner_product(bits, [1,2,4,..])
+        uint64_t acc = bits[0]; cell64(bits[0]);
+        for (int i = 1; i < n; i++) { acc += bits[i] << i; cell64(bits[i]); sink.cell(fr_pow2(i)); cell64(acc); }
+        return acc;
+    }
+    HNI void range_check(Gl a, int bits) {                 // RangeChip::range_check on a 64-bit value
+        const int L = cfg.L; if (bits == 0) return;
+        const int n = (bits + L - 1) / L, rem = bits % L; uint64_t last = a;
+        const uint64_t lm = (1ull << L) - 1;
+        if (n > 1) {
+            cell64(a & lm);
+            for (int j = 1; j < n; j++) {
+                uint64_t limb = (j * L >= 64) ? 0 : (a >> (j * L)) & lm;
+                cell64(limb); sink.cell(fr_pow2(j * L)); cell64((j + 1) * L >= 64 ? a : a & ((1ull << ((j + 1) * L)) - 1));
+                last = limb;
+            }
+        }
+        if (rem == 1) { cell64(0); cell64(last); cell64(last); cell64(last); }
+        else if (rem > 1) { cell64(0); cell64(last); sink.cell(fr_pow2(L - rem)); sink.cell(fr_from_u128((u128)last << (L - rem))); }
+    }
+    // ---------------------------------------------------------------- native Fr templates (BN254 Poseidon): direct cells
+    HF Fr fr_const(const fr_t &v) { cell(v); return v; }
+    HF Fr fr_witness(const fr_t &v) { cell(v); return v; }
+    HF Fr fr_load_zero() { if (!zero_cached) { cell64(0); zero_cached = true; } return fr_zero(); }
+    HF void fr_zero_consts4(Fr *st) { for (int i = 0; i < 4; i++) { cell64(0); st[i] = fr_zero(); } }
+    HNI Fr fr_add(const Fr &a, const Fr &b) { Fr v = h2w::fr_add(a, b); cell(a); cell(b); cell64(1); cell(v); return v; }
+    HNI Fr fr_mul(const Fr &a, const Fr &b) { Fr v = h2w::fr_mul(a, b, cfg.P); cell64(0); cell(a); cell(b); cell(v); return v; }
+    HNI Fr fr_mul_add(const Fr &a, const Fr &b, const Fr &c) { Fr v = h2w::fr_add(h2w::fr_mul(a, b, cfg.P), c); cell(c); cell(a); cell(b); cell(v); return v; }
+    HNI Fr fr_select(const Fr &a, const Fr &b, Bool sel) {
+        Fr diff = fr_sub(a, b); Fr out = sel ? a : b;
+        cell(diff); cell64(1); cell(b); cell(a); cell(b); cell64(sel); cell(diff); cell(out);
+        return out;
+    }
+    HNI Fr fr_select_from_idx(const Fr *col, int n, Gl idx) {
+        Bool ind[MAX_CAP]; idx_to_indicator(idx, n, ind);
+        Fr sum = fr_zero(); cell64(0);
+        for (int i = 0; i < n; i++) { if (ind[i]) sum = h2w::fr_add(sum, col[i]); cell(col[i]); cell64(ind[i]); cell(sum); }
+        return sum;
+    }
+    HF Fr limbs_to_num(const Gl *in, int n) {             // RangeChip::limbs_to_num(limbs, 64)
+        Fr acc = fr_zero(); acc.l[0] = in[0]; cell64(in[0]);
+        for (int i = 1; i < n; i++) { acc.l[i] = in[i]; cell64(in[i]); sink.cell(fr_pow2(64 * i)); cell(acc); }
+        return acc;
+    }
+    HNI void decompose_le_56_5(const Fr &x, Gl *out) {     // RangeChip::decompose_le(x, 56, 5)
+        for (int i = 0; i < 5; i++) out[i] = fr_bits(x, 56 * i, 56);
+        cell64(out[0]);
+        for (int i = 1; i < 5; i++) {
+            cell64(out[i]); sink.cell(fr_pow2(56 * i));
+            Fr acc = x; const int hb = 56 * (i + 1);                 // x mod 2^(56(i+1))
+            if (hb < 256) { const int w = hb >> 6, sh = hb & 63; for (int j = w + 1; j < 4; j++) acc.l[j] = 0; acc.l[w] &= sh ? ((1ull << sh) - 1) : 0; }
+            cell(acc);
+        }
+        for (int i = 0; i < 5; i++) range_check(out[i], 56);
+    }
+    // ---------------------------------------------------------------- proof wires (flat layout, verifier.h ProofLayout)
+    HF Gl proof_gl(uint64_t w) { return cfg.proof[w]; }
+    HF HashW<ValBackend> proof_hash(uint64_t w) {
+        HashW<ValBackend> h;
+        if (cfg.mode == 0) { for (int i = 0; i < 4; i++) h.e[i] = cfg.proof[w + i]; h.f = fr_zero(); }
+        else { for (int i = 0; i < 4; i++) { h.f.l[i] = cfg.proof[w + i]; h.e[i] = 0; } }
+        return h;
+    }
+    HF void load_proof_gl(uint64_t w) { gl_witness(cfg.proof[w]); }
+    HF void load_proof_gl_nocheck(uint64_t w) { sink.rec(T_CONST1, cfg.proof[w], 0, 0, 0); }
+    HF void load_proof_hash(uint64_t w) {
+        if (cfg.mode == 0) sink.rec(T_CONST4, cfg.proof[w], cfg.proof[w + 1], cfg.proof[w + 2], cfg.proof[w + 3]);
+        else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = cfg.proof[w + i]; cell(v); }
+    }
+    // ---------------------------------------------------------------- strand hooks
+    HF bool merkle_split(int q, int kind) {
+        if (!cfg.split) return false;
+        const int s = q == 0 ? 0 : 1;
+        sink.skip(cfg.st->mk_nrec[s][kind], cfg.st->mk_ncell[s][kind]);
+        return true;
+    }
+    HF void merkle_begin(int q, int kind) { sink.merkle_begin(q, kind, zero_cached); }
+    HF void merkle_end(int q, int kind) { sink.merkle_end(q, kind, zero_cached); }
+    HF void query_begin(int q) { sink.query_begin(q); }
+    HF void query_end(int q) { sink.query_end(q); }
+};
+
+// device sink: records into this proof's record array, direct cells into this proof's advice range
+struct DevSink {
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells;
+    HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec++] = r; cell_off += ncells[t]; }
+    HF void cell(const fr_t &v) { out[cell_off++] = v; }
+    HF void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
+    HF void merkle_begin(int, int, bool) {}
+    HF void merkle_end(int, int, bool) {}
+    HF void query_begin(int) {}
+    HF void query_end(int) {}
+};
+
+}  // namespace h2w

@@ -1,0 +1,245 @@
+// verifier.h — protocol layer (L5) over chips.h: WitnessChip, ChallengerChip, FriChip, StarkChip.
+// Same single-source scheme as chips.h.  The top-level flow of the reference test
+// (stark/mod.rs:483-508: permutation_chip.load_zero; load_proof_with_pis; StarkChip::verify_proof) is cut into
+// *strands* whose cell ranges are independent once the Fiat-Shamir challenges are known:
+//     prologue (per proof)   : zero state, witness load, get_stark_challenges, fri_instance_info, PoW, from_os_and_alpha
+//     query    (per query)   : FriChip::verify_query_round minus its Merkle proofs
+//     merkle   (per query x tree) : MerkleTreeChip::verify_proof_to_cap_with_cap_index
+// A sequential backend (plan / eager ABI) runs them in the reference order; the device runs one lane per strand.
+#pragma once
+#include "chips.h"
+
+namespace h2w {
+
+constexpr int MAX_QUERIES = 128;
+constexpr int CH_BUF = 2 * MAX_FINAL_POLY + 16;
+constexpr int MK_KINDS = 3 + MAX_STEPS;   // merkle strand kinds: initial oracle o (0..2), fold step i (3+i)
+
+// wires produced by the prologue and consumed by the query strands (fri/mod.rs:64-69 FriChallengesWire + instance points)
+template <class B> struct ChallengeBlock {
+    ExtW<B> zeta, zeta_next, fri_alpha, fri_betas[MAX_STEPS], reduced_openings[2];
+    typename B::Gl fri_pow_response;
+    typename B::Gl fri_query_indices[MAX_QUERIES];
+};
+
+// =========================================================================== ChallengerChip (challenger/mod.rs)
+template <class B> struct ChallengerChip {
+    typedef typename B::Gl Gl; typedef HashW<B> H;
+    B &be; PoseidonPermutationChip<B> pg; HasherChip<B> &hs;
+    Gl state[SPONGE_WIDTH]; Gl in[CH_BUF]; int n_in; Gl out[SPONGE_RATE]; int n_out;
+    HF ChallengerChip(B &b, HasherChip<B> &h, const h2w_poseidon_consts_t *k) : be(b), pg(b, k), hs(h), n_in(0), n_out(0) {}
+    HF void observe_element(Gl t) { n_out = 0; if (n_in < CH_BUF) in[n_in++] = t; else be.fail(3); }     // :45-50
+    HF void observe_hash(const H &h) { Gl v[5]; int n = hs.to_goldilocks_vec(h, v); for (int i = 0; i < n; i++) observe_element(v[i]); } // :59-63
+    HF void observe_extension_element(const ExtW<B> &e) { observe_element(e.e[0]); observe_element(e.e[1]); }   // :76-78
+    HNI void absorb_buffered_inputs() {                                                                 // :260-277
+        if (n_in == 0) return;
+        pg.absorb_goldilocks(state, in, n_in);
+        for (int i = 0; i < SPONGE_RATE; i++) out[i] = state[i];
+        n_out = SPONGE_RATE; n_in = 0;
+    }
+    HNI Gl get_challenge() {                                                                            // :92-108
+        absorb_buffered_inputs();
+        if (n_out == 0) { pg.permute(state); for (int i = 0; i < SPONGE_RATE; i++) out[i] = state[i]; n_out = SPONGE_RATE; }
+        return out[--n_out];
+    }
+    HF ExtW<B> get_extension_challenge() { ExtW<B> r; r.e[0] = get_challenge(); r.e[1] = get_challenge(); return r; }  // :119-126
+};
+
+// =========================================================================== the verifier, strand by strand
+template <class B> struct Verifier {
+    typedef typename B::Gl Gl; typedef typename B::Bool Bool; typedef typename B::Fr Fr; typedef ExtW<B> Ex; typedef HashW<B> H;
+    B &be; const h2w_shape_t &s; const h2w_poseidon_consts_t *k; Derived d; ProofLayout pl;
+    GoldilocksChip<B> gl; QuadExtChip<B> ext; HasherChip<B> hs; MerkleTreeChip<B> mk;
+    HF Verifier(B &b, const h2w_shape_t &sh, const h2w_poseidon_consts_t *kk)
+        : be(b), s(sh), k(kk), d(derive_shape(sh)), pl(proof_layout(sh, derive_shape(sh))), gl(b), ext(b), hs(b, sh.hash_mode, kk), mk(b, sh.hash_mode, kk) {}
+
+    HF Ex proof_ext(uint64_t w) { Ex e; e.e[0] = be.proof_gl(w); e.e[1] = be.proof_gl(w + 1); return e; }
+    // ---- WitnessChip::load_proof_with_pis (witness/mod.rs:267-294), in flat-layout order
+    HF void load_gl(uint64_t w) { if (s.witness_load_range_check) be.load_proof_gl(w); else be.load_proof_gl_nocheck(w); }   // :48-51
+    HNI void load_proof_with_pis() {
+        uint64_t w = 0;
+        for (int i = 0; i < 2 * d.cap_size; i++, w += 4) be.load_proof_hash(w);                 // trace_cap, quotient_polys_cap (:245-246)
+        uint64_t n_open = 2ull * (2 * s.n_cols + 2 * s.n_perm_z + s.n_quotient);
+        for (uint64_t i = 0; i < n_open; i++, w++) load_gl(w);                                  // load_openings_set (:129-147)
+        if (s.n_perm_z > 0) for (int i = 0; i < d.cap_size; i++, w += 4) be.load_proof_hash(w); // permutation_zs_cap (:251-254)
+        load_gl(w++);                                                                           // pow_witness (:155)
+        for (int i = 0; i < 2 * d.final_poly_len; i++, w++) load_gl(w);                         // final_poly (:157-164)
+        for (int i = 0; i < d.n_steps * d.cap_size; i++, w += 4) be.load_proof_hash(w);         // commit_phase_merkle_caps (:166-170)
+        for (int q = 0; q < s.num_queries; q++) {                                               // query_round_proofs (:172-225)
+            for (int o = 0; o < d.n_oracles; o++) {
+                for (int i = 0; i < d.oracle_polys[o]; i++, w++) load_gl(w);
+                for (int i = 0; i < pl.init_sibs; i++, w += 4) be.load_proof_hash(w);
+            }
+            for (int st = 0; st < d.n_steps; st++) {
+                for (int i = 0; i < (2 << d.arity[st]); i++, w++) load_gl(w);
+                for (int i = 0; i < pl.step_sibs[st]; i++, w += 4) be.load_proof_hash(w);
+            }
+        }
+        for (int i = 0; i < s.n_pis; i++, w++) load_gl(w);                                      // public inputs (:285-288)
+    }
+    HF void observe_cap(ChallengerChip<B> &ch, uint64_t w0) { for (int i = 0; i < d.cap_size; i++) ch.observe_hash(be.proof_hash(w0 + 4ull * i)); } // challenger/mod.rs:65-74
+    // openings in to_fri_openings() order (stark/mod.rs:48-69): zeta batch = local, perm_zs, quotient ; zeta_next batch = next, perm_zs_next
+    HF uint64_t zeta_word(int i) const {
+        uint64_t o = pl.openings;
+        if (i < s.n_cols) return o + 2ull * i;
+        i -= s.n_cols; if (i < s.n_perm_z) return o + 2ull * (2 * s.n_cols + i);
+        i -= s.n_perm_z; return o + 2ull * (2 * s.n_cols + 2 * s.n_perm_z + i);
+    }
+    HF uint64_t zeta_next_word(int i) const {
+        uint64_t o = pl.openings;
+        if (i < s.n_cols) return o + 2ull * (s.n_cols + i);
+        i -= s.n_cols; return o + 2ull * (2 * s.n_cols + s.n_perm_z + i);
+    }
+    // ---- prologue strand
+    HF void prologue(ChallengeBlock<B> &cb) {
+        ChallengerChip<B> ch(be, hs, k);
+        ch.pg.load_zero(ch.state);                                   // stark/mod.rs:497-499
+        load_proof_with_pis();                                       // stark/mod.rs:506
+        // ChallengerChip::get_stark_challenges (challenger/mod.rs:167-222)
+        observe_cap(ch, pl.trace_cap);
+        if (s.n_perm_z > 0) {
+            for (int i = 0; i < s.perm_batch_size * s.num_challenges * 2; i++) ch.get_challenge();   // get_n_permutation_challenge_sets (:224-256)
+            observe_cap(ch, pl.perm_cap);
+        }
+        for (int i = 0; i < s.num_challenges; i++) ch.get_challenge();                               // stark_alphas (:203)
+        observe_cap(ch, pl.quotient_cap);
+        cb.zeta = ch.get_extension_challenge();                                                     // :206
+        const int nz = s.n_cols + s.n_perm_z + s.n_quotient, nzn = s.n_cols + s.n_perm_z;
+        for (int i = 0; i < nz; i++) ch.observe_extension_element(proof_ext(zeta_word(i)));          // observe_openings (:208)
+        for (int i = 0; i < nzn; i++) ch.observe_extension_element(proof_ext(zeta_next_word(i)));
+        // get_fri_challenges (:128-165)
+        cb.fri_alpha = ch.get_extension_challenge();
+        for (int i = 0; i < d.n_steps; i++) { observe_cap(ch, pl.commit_caps + (uint64_t)i * d.cap_size * 4); cb.fri_betas[i] = ch.get_extension_challenge(); }
+        for (int i = 0; i < d.final_poly_len; i++) ch.observe_extension_element(proof_ext(pl.final_poly + 2ull * i));
+        ch.observe_element(be.proof_gl(pl.pow_witness));
+        cb.fri_pow_response = ch.get_challenge();
+        for (int i = 0; i < s.num_queries; i++) cb.fri_query_indices[i] = ch.get_challenge();
+        // verify_proof_with_challenges: fri_instance_info (stark/mod.rs:144-200): zeta_next = g * zeta
+        { gle_t gv; gv.c[0] = gl_primitive_root_of_unity(s.degree_bits); gv.c[1] = 0; Ex g = ext.load_constant(gv); cb.zeta_next = ext.mul(g, cb.zeta); }
+        // FriChip::verify_fri_proof (fri/mod.rs:446-502): PoW (:130-145), from_os_and_alpha (:45-62)
+        be.range_check(cb.fri_pow_response, 64 - s.pow_bits);
+        cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { return proof_ext(zeta_word(i)); }, cb.fri_alpha);
+        cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { return proof_ext(zeta_next_word(i)); }, cb.fri_alpha);
+    }
+    // ---- merkle strand: kind < 3: initial oracle `kind`; kind >= 3: fold step kind-3.  bits/cap_index are wires of the query.
+    HF uint64_t query_word(int q) const { return pl.queries + (uint64_t)q * pl.query_words; }
+    HF uint64_t initial_cap_word(int o) const {   // merkle_caps = [trace, perm_zs?, quotient] (stark/mod.rs:323-326)
+        if (o == 0) return pl.trace_cap;
+        if (s.n_perm_z > 0 && o == 1) return pl.perm_cap;
+        return pl.quotient_cap;
+    }
+    HF void merkle_strand(int q, int kind, const Bool *bits, int n_bits, Gl cap_index) {
+        const uint64_t qw = query_word(q);
+        if (kind < 3) {
+            const int o = kind; const uint64_t base = qw + pl.init_off[o]; const int ne = d.oracle_polys[o];
+            Gl leaf[MAX_BATCH_POLYS]; for (int i = 0; i < ne; i++) leaf[i] = be.proof_gl(base + i);
+            const uint64_t capw = initial_cap_word(o), sibw = base + ne;
+            mk.verify_proof_to_cap_with_cap_index(leaf, ne, bits, n_bits, cap_index, d.cap_size,
+                [&](int i) { return be.proof_hash(capw + 4ull * i); }, pl.init_sibs, [&](int i) { return be.proof_hash(sibw + 4ull * i); });
+        } else {
+            const int st = kind - 3; const uint64_t base = qw + pl.step_off[st]; const int ne = 2 << d.arity[st];
+            Gl leaf[2 * MAX_ARITY]; for (int i = 0; i < ne; i++) leaf[i] = be.proof_gl(base + i);
+            const uint64_t capw = pl.commit_caps + (uint64_t)st * d.cap_size * 4, sibw = base + ne;
+            mk.verify_proof_to_cap_with_cap_index(leaf, ne, bits, n_bits, cap_index, d.cap_size,
+                [&](int i) { return be.proof_hash(capw + 4ull * i); }, pl.step_sibs[st], [&](int i) { return be.proof_hash(sibw + 4ull * i); });
+        }
+    }
+    HF void merkle_call(int q, int kind, const Bool *bits, int n_bits, Gl cap_index) {
+        if (be.merkle_split(q, kind)) return;      // device: cells of this call belong to a merkle strand
+        be.merkle_begin(q, kind); merkle_strand(q, kind, bits, n_bits, cap_index); be.merkle_end(q, kind);
+    }
+    // ---- FriChip pieces (fri/mod.rs)
+    HNI Ex combine_initial(int q, const ChallengeBlock<B> &cb, Gl subgroup_x) {                       // :169-220
+        const uint64_t qw = query_word(q);
+        Ex sx = ext.load_base(subgroup_x);
+        Ex sum = ext.load_zero();
+        for (int b = 0; b < 2; b++) {
+            const int np = b == 0 ? s.n_cols + s.n_perm_z + s.n_quotient : s.n_cols + s.n_perm_z;
+            Ex evals[MAX_BATCH_POLYS];
+            for (int i = 0; i < np; i++) {     // FriPolynomialInfo order of fri_instance_info (stark/mod.rs:157-196)
+                int o, pi, t = i;
+                if (t < s.n_cols) { o = 0; pi = t; }
+                else { t -= s.n_cols; if (t < s.n_perm_z) { o = 1; pi = t; } else { t -= s.n_perm_z; o = s.n_perm_z > 0 ? 2 : 1; pi = t; } }
+                evals[i] = ext.load_base(be.proof_gl(qw + pl.init_off[o] + pi));
+            }
+            Ex reduced_evals = ext.reduce_with_powers(np, [&](int i) { return evals[i]; }, cb.fri_alpha);
+            Ex numerator = ext.sub(reduced_evals, cb.reduced_openings[b]);
+            Ex denominator = ext.sub(sx, b == 0 ? cb.zeta : cb.zeta_next);
+            Ex denominator_inv = ext.inv(denominator);
+            Ex alpha_shift = ext.exp_u64(cb.fri_alpha, (uint64_t)np);
+            sum = ext.mul(alpha_shift, sum);
+            sum = ext.mul_add(numerator, denominator_inv, sum);
+        }
+        return sum;
+    }
+    HNI Ex interpolate_coset(Gl coset_shift, const Ex *values, int n, const Ex &evaluation_point) {   // :222-283
+        int arity_bits = 0; while ((1 << arity_bits) < n) arity_bits++;
+        Ex shifted = ext.scalar_div(evaluation_point, coset_shift);
+        uint64_t dom[MAX_ARITY]; const uint64_t g = gl_primitive_root_of_unity(arity_bits);
+        dom[0] = 1; for (int i = 1; i < n; i++) dom[i] = gl_mul(dom[i - 1], g);          // two_adic_subgroup
+        Ex domain[MAX_ARITY]; Gl bw[MAX_ARITY]; Ex wv[MAX_ARITY];
+        for (int i = 0; i < n; i++) { gle_t e; e.c[0] = dom[i]; e.c[1] = 0; domain[i] = ext.load_constant(e); }
+        for (int i = 0; i < n; i++) {                                                     // barycentric_weights
+            uint64_t pr = 1; for (int j = 0; j < n; j++) if (j != i) pr = gl_mul(pr, gl_sub(dom[i], dom[j]));
+            bw[i] = gl.load_constant(gl_inv(pr));
+        }
+        for (int i = 0; i < n; i++) wv[i] = ext.scalar_mul(values[i], bw[i]);
+        Ex eval = ext.load_zero(), tpp = ext.load_one();
+        for (int i = 0; i < n; i++) {
+            Ex term = ext.sub(shifted, domain[i]);
+            Ex next_tpp = ext.mul(tpp, term);
+            Ex tmp1 = ext.mul(eval, term), tmp2 = ext.mul(wv[i], tpp);
+            eval = ext.add(tmp1, tmp2); tpp = next_tpp;
+        }
+        return eval;
+    }
+    HF Ex compute_evaluation(Gl x, const Bool *within_bits, int arity_bits, const Ex *evals_in, const Ex &beta) {  // :285-322
+        const int arity = 1 << arity_bits;
+        const uint64_t g = gl_primitive_root_of_unity(arity_bits), g_inv = gl_exp(g, (uint64_t)arity - 1);
+        Ex evals[MAX_ARITY];
+        for (int i = 0; i < arity; i++) { int r = 0; for (int b = 0; b < arity_bits; b++) if (i & (1 << b)) r |= 1 << (arity_bits - 1 - b); evals[r] = evals_in[i]; }
+        Bool rev[8]; for (int i = 0; i < arity_bits; i++) rev[i] = within_bits[arity_bits - 1 - i];
+        Gl start = gl.exp_from_bits_const_base(g_inv, rev, arity_bits);
+        Gl coset_start = gl.mul(start, x);
+        return interpolate_coset(coset_start, evals, arity, beta);
+    }
+    // ---- query strand: FriChip::verify_query_round (fri/mod.rs:337-444)
+    HF void query_round(int q, const ChallengeBlock<B> &cb) {
+        const int n_log = d.lde_bits; const uint64_t qw = query_word(q);
+        Bool bits64[64];
+        gl.num_to_bits(cb.fri_query_indices[q], 64, bits64);                 // :363
+        Bool *x_index_bits = bits64; int nb = n_log;                         // truncate(n_log)
+        Gl cap_index = gl.bits_to_num(x_index_bits + nb - s.cap_height, s.cap_height);   // :366-369
+        for (int o = 0; o < d.n_oracles; o++) merkle_call(q, o, x_index_bits, nb, cap_index);   // verify_initial_proof (:147-167)
+        Gl subgroup_x;
+        {   // :379-389
+            Gl g = gl.load_constant(7);
+            Bool rev[64]; for (int i = 0; i < nb; i++) rev[i] = x_index_bits[nb - 1 - i];
+            Gl phi = gl.exp_from_bits_const_base(gl_primitive_root_of_unity(n_log), rev, nb);
+            subgroup_x = gl.mul(g, phi);
+        }
+        Ex old_eval = combine_initial(q, cb, subgroup_x);
+        for (int i = 0; i < d.n_steps; i++) {                                // :403-438
+            const int ab = d.arity[i]; const int ne = 1 << ab; const uint64_t ew = qw + pl.step_off[i];
+            Ex evals[MAX_ARITY]; for (int j = 0; j < ne; j++) evals[j] = proof_ext(ew + 2ull * j);
+            Bool *coset_index_bits = x_index_bits + ab; const int ncb = nb - ab;
+            Gl within = gl.bits_to_num(x_index_bits, ab);
+            ext.select_from_idx(evals, ne, within);                         // new_eval; assert_equal(new_eval, old_eval): no cells
+            old_eval = compute_evaluation(subgroup_x, x_index_bits, ab, evals, cb.fri_betas[i]);
+            merkle_call(q, 3 + i, coset_index_bits, ncb, cap_index);
+            subgroup_x = gl.exp_power_of_2(subgroup_x, ab);
+            x_index_bits = coset_index_bits; nb = ncb;
+        }
+        {   // eval_scalar (:324-335)
+            Ex point = ext.load_base(subgroup_x);
+            ext.reduce_with_powers(d.final_poly_len, [&](int i) { return proof_ext(pl.final_poly + 2ull * i); }, point);
+        }
+    }
+    // bits / cap_index of query q's merkle strand `kind`, recomputed from the challenge value (device merkle lanes)
+    HF void run_all(ChallengeBlock<B> &cb) {        // sequential backends: the reference order
+        prologue(cb);
+        for (int q = 0; q < s.num_queries; q++) { be.query_begin(q); query_round(q, cb); be.query_end(q); }
+    }
+};
+
+}  // namespace h2w

@@ -1,0 +1,161 @@
+/*
+ * h2w.h — C ABI of the MI355X-native halo2 witness-generation engine for the plonky2/starky
+ * FRI-verifier gadget (drop-in for ONE hot path of shuklaayush/halo2-plonky2-verifier).
+ *
+ * The boundary sits below the reference's NativeChip (verifier/src/field/native.rs:11-194) /
+ * ContextWrapper.ctx (verifier/src/util/context_wrapper.rs:11-26), i.e. where the Rust code calls
+ * halo2-base Context / GateChip / RangeChip.  Three API levels, all producing the SAME advice stream:
+ *
+ *   1. eager NativeChip level  (h2w_load_*, h2w_add ... h2w_range_check)   — 1:1 with field/native.rs
+ *   2. fused Goldilocks level  (h2w_gl_*)                                  — field/goldilocks/base.rs ops
+ *      (hints — u128 divmod, GL inverse — run inside the library)
+ *   3. batched hot path        (h2w_plan_* / h2w_fri_witness_batch)        — whole
+ *      load_proof_with_pis + StarkChip::verify_proof (stark/mod.rs:483-508) for a batch of proofs,
+ *      values and cells computed on the GPU.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All functions returning int return 0 on
+ * success; on failure h2w_last_error() describes it (the reference panics instead; the Rust shim
+ * in INTEGRATION.md converts non-zero to panic!).  Handles are not thread-safe; distinct handles
+ * are independent (the reference is single-threaded: one &mut Context).
+ *
+ * Advice cells are BN254 Fr values, 32 bytes each, canonical little-endian (4 x u64 limbs).
+ */
+#ifndef H2W_H
+#define H2W_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2W_ABI_VERSION 1
+
+typedef struct { uint64_t l[4]; } h2w_fr_t;
+
+/* mirrors halo2-base AssignedValue{value, cell: Option<ContextCell{context_id, offset}>} */
+typedef struct {
+    h2w_fr_t value;
+    uint64_t offset;     /* row in Context::advice */
+    uint32_t ctx_id;
+    uint32_t has_cell;   /* 0 = value only (QuantumCell::Witness/Constant not yet assigned) */
+} h2w_assigned_t;
+
+/* STARK / FRI shape: starky StarkConfig + the Stark trait facts the verifier needs
+ * (stark/mod.rs:145-200, challenger/mod.rs:168-222, fri/mod.rs:447-502). */
+typedef struct {
+    int32_t degree_bits, rate_bits, cap_height, num_queries, pow_bits, num_challenges;
+    int32_t arity_bits, final_poly_bits;          /* FriReductionStrategy::ConstantArityBits */
+    int32_t n_cols, n_perm_z, n_quotient, n_pis;  /* Fibonacci: 4, 2, 2, 3 */
+    int32_t perm_batch_size;
+    int32_t hash_mode;                            /* 0 = Goldilocks Poseidon Merkle, 1 = PoseidonBN254 Merkle */
+    int32_t lookup_bits;                          /* RangeChip lookup_bits (= k-1) */
+    int32_t witness_load_range_check;             /* 1 = witness/mod.rs:49-51 (28 cells / GL element) */
+} h2w_shape_t;
+
+/* Poseidon constants are caller inputs (plonky2 `hash::poseidon`, plonky2x `poseidon_bn128_constants`);
+ * indexing as hash/poseidon/permutation.rs:55-68,97-104,120-130,143-171,184-192,229-235 and
+ * hash/poseidon_bn254/permutation.rs:86-109,138-159,163-170. */
+typedef struct {
+    uint64_t all_round_constants[360];
+    uint64_t mds_circ[12];
+    uint64_t mds_diag[12];
+    uint64_t fast_partial_first_round_constant[12];
+    uint64_t fast_partial_round_constants[22];
+    uint64_t fast_partial_round_initial_matrix[11][11];
+    uint64_t fast_partial_round_w_hats[22][11];
+    uint64_t fast_partial_round_vs[22][11];
+    h2w_fr_t bn_c[88];
+    h2w_fr_t bn_s[392];
+    h2w_fr_t bn_m[4][4];
+    h2w_fr_t bn_p[4][4];
+} h2w_poseidon_consts_t;
+
+typedef struct h2w_ctx h2w_ctx;
+typedef struct h2w_plan h2w_plan;
+
+/* ------------------------------------------------------------------ library */
+int         h2w_abi_version(void);
+const char *h2w_last_error(void);
+int         h2w_device_count(void);              /* number of visible HIP devices (0 = none: every compute call fails) */
+
+/* ------------------------------------------------------------------ 1. eager NativeChip level
+ * replaces halo2-base Context + GateChip + RangeChip as used by field/native.rs.
+ * Values are computed on the host at call time (the reference reads AssignedValue::value() for hints:
+ * base.rs:27-35,349,382); cells are materialised on the GPU from compact records when the advice is
+ * requested (h2w_ctx_advice_device / h2w_ctx_download). */
+h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id);   /* base_test().k(k): lookup_bits = k-1 */
+void     h2w_ctx_free(h2w_ctx *);
+uint64_t h2w_num_cells(const h2w_ctx *);                                        /* util/context_wrapper.rs:24-26 */
+int      h2w_ctx_error(const h2w_ctx *);                                        /* sticky error flag of the context */
+/* field/native.rs:28-46 */
+int h2w_load_constant(h2w_ctx *, const h2w_fr_t *c, h2w_assigned_t *out);
+int h2w_load_zero(h2w_ctx *, h2w_assigned_t *out);
+int h2w_load_constants(h2w_ctx *, const h2w_fr_t *c, size_t n, h2w_assigned_t *out);
+int h2w_load_witness(h2w_ctx *, const h2w_fr_t *w, h2w_assigned_t *out);
+/* field/native.rs:48-92 */
+int h2w_add(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);
+int h2w_mul(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);
+int h2w_mul_add(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *c, h2w_assigned_t *out);
+int h2w_select(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *sel, h2w_assigned_t *out);
+/* field/native.rs:95-148 */
+int h2w_select_from_idx(h2w_ctx *, const h2w_assigned_t *arr, size_t n, const h2w_assigned_t *idx, h2w_assigned_t *out);
+int h2w_select_array_by_indicator(h2w_ctx *, const h2w_assigned_t *array2d /* [len][w] row-major */, size_t len, size_t w,
+                                  const h2w_assigned_t *indicator, h2w_assigned_t *out /* [w] */);
+int h2w_idx_to_indicator(h2w_ctx *, const h2w_assigned_t *idx, size_t len, h2w_assigned_t *out);
+int h2w_num_to_bits(h2w_ctx *, const h2w_assigned_t *a, size_t range_bits, h2w_assigned_t *out);
+int h2w_bits_to_num(h2w_ctx *, const h2w_assigned_t *bits, size_t n, h2w_assigned_t *out);
+/* field/native.rs:150-193 */
+int h2w_decompose_le(h2w_ctx *, const h2w_assigned_t *num, size_t limb_bits, size_t num_limbs, h2w_assigned_t *out);
+int h2w_limbs_to_num(h2w_ctx *, const h2w_assigned_t *limbs, size_t n, size_t limb_bits, h2w_assigned_t *out);
+int h2w_check_less_than_safe(h2w_ctx *, const h2w_assigned_t *a, uint64_t b);
+int h2w_range_check(h2w_ctx *, const h2w_assigned_t *a, size_t range_bits);
+int h2w_constrain_equal(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b); /* Context::constrain_equal: no cells */
+
+/* ------------------------------------------------------------------ 2. fused Goldilocks level
+ * field/goldilocks/base.rs: one call = the whole cell block of the op, hint included. */
+int h2w_gl_load_constant(h2w_ctx *, uint64_t a, h2w_assigned_t *out);            /* base.rs:61-70   (1 cell)  */
+int h2w_gl_load_witness(h2w_ctx *, uint64_t a, h2w_assigned_t *out);             /* base.rs:107-119 (28 @L=21) */
+int h2w_gl_reduce(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);      /* base.rs:346-368 (61) */
+int h2w_gl_add(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);     /* :251-260 (65) */
+int h2w_gl_sub(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);     /* :274-283 (66) */
+int h2w_gl_mul(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);     /* :296-305 (65) */
+int h2w_gl_mul_add(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *c, h2w_assigned_t *out); /* :319-329 */
+int h2w_gl_div(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);     /* :371-393 (93); error if b == 0 (:379) */
+int h2w_gl_inv(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                              /* :395-399 (94) */
+
+/* ------------------------------------------------------------------ advice hand-off (eager contexts) */
+/* Expands all pending records on the GPU; *dev_ptr receives a device pointer to num_cells*32 bytes
+ * owned by the context (valid until the next h2w_* call on it). */
+int h2w_ctx_advice_device(h2w_ctx *, void **dev_ptr);
+/* Copies cells [first, first+count) to host memory (expanding on the GPU first). */
+int h2w_ctx_download(h2w_ctx *, uint64_t first, uint64_t count, h2w_fr_t *host_dst);
+
+/* ------------------------------------------------------------------ 3. batched hot path */
+/* Shape compile: replays the gadget once (host) to lay out every cell block of
+ * load_proof_with_pis + verify_proof for this shape; uploads tables + constants to `device_id`. */
+h2w_plan *h2w_plan_compile(const h2w_shape_t *, const h2w_poseidon_consts_t *, int device_id);
+void      h2w_plan_free(h2w_plan *);
+uint64_t  h2w_plan_num_cells(const h2w_plan *);         /* advice cells per proof */
+uint64_t  h2w_plan_proof_words(const h2w_plan *);       /* u64 words per flat proof (layout: INTEGRATION.md) */
+uint64_t  h2w_plan_num_records(const h2w_plan *);
+/* Scratch bytes the batch call needs on the device for n_proofs (records, challenge blocks, traces). */
+uint64_t  h2w_plan_workspace_bytes(const h2w_plan *, uint64_t n_proofs);
+/* proofs_dev:  n_proofs * proof_words u64, device memory.
+ * advice_dev:  n_proofs * num_cells * 32 bytes, device memory (canonical LE Fr).
+ * workspace_dev: h2w_plan_workspace_bytes bytes, device memory.
+ * stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
+int h2w_fri_witness_batch(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs,
+                          void *advice_dev, void *workspace_dev, void *stream);
+/* Per-proof device status words (0 = ok; non-zero = reference would have panicked, e.g. inverse of zero) */
+int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
+/* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */
+int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);
+/* Timing of the last batch call's kernels in ms via HIP events recorded on `stream`
+ * (index: 0 = value pass, 1 = expansion, 2 = total).  Blocks until the batch finished. */
+int h2w_plan_last_timing(h2w_plan *, float ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

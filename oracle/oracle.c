@@ -10,7 +10,8 @@
 #include <assert.h>
 
 /* ===================================================================== context */
-typedef struct { int64_t a, b; int kind; } oeq_t;        /* kind 0 = internal, 1 = semantic (chip assert) */
+typedef struct { int64_t a, b; int kind; } oeq_t;
+typedef struct { int64_t cell; int kind; } olk_t;        /* kind 0 = internal, 1 = semantic (chip assert) */
 typedef struct { int64_t cell; ofr_t c; } oceq_t;
 typedef struct { int parent; int name; uint64_t cells; int first_child, next_sibling; } onode_t;
 
@@ -20,13 +21,14 @@ struct octx {
     uint8_t *selector; size_t selcap;
     oeq_t *eq; size_t neq, capeq;
     oceq_t *ceq; size_t nceq, capceq;
-    int64_t *lookup; size_t nlookup, caplookup;
+    olk_t *lookup; size_t nlookup, caplookup;
     int64_t zero_cell;
     /* scope tree (util/context_tree.rs) */
     onode_t *nodes; int nnodes, capnodes; int cur;
     uint64_t *enter; int depth, capdepth;
     char **names; int nnames, capnames;
     char err[256]; int failed;
+    int semantic; /* >0: constraints registered now are protocol checks on the (possibly invalid) proof */
 };
 
 enum { QC_EXISTING = 0, QC_WITNESS = 1, QC_CONSTANT = 2 };
@@ -114,7 +116,7 @@ static inline void adv_push(octx_t *c, const ofr_t *v) {
 static void add_eq(octx_t *c, int64_t a, int64_t b, int kind) {
     if (c->witness_gen_only) return;
     if (c->neq == c->capeq) { c->capeq = c->capeq ? c->capeq * 2 : 1024; c->eq = (oeq_t *)realloc(c->eq, c->capeq * sizeof(oeq_t)); }
-    c->eq[c->neq].a = a; c->eq[c->neq].b = b; c->eq[c->neq].kind = kind; c->neq++;
+    c->eq[c->neq].a = a; c->eq[c->neq].b = b; c->eq[c->neq].kind = c->semantic ? 1 : kind; c->neq++;
 }
 static void add_ceq(octx_t *c, int64_t cell, const ofr_t *v) {
     if (c->witness_gen_only) return;
@@ -123,8 +125,8 @@ static void add_ceq(octx_t *c, int64_t cell, const ofr_t *v) {
 }
 static void add_lookup(octx_t *c, int64_t cell) {
     if (c->witness_gen_only) return;
-    if (c->nlookup == c->caplookup) { c->caplookup = c->caplookup ? c->caplookup * 2 : 1024; c->lookup = (int64_t *)realloc(c->lookup, c->caplookup * sizeof(int64_t)); }
-    c->lookup[c->nlookup++] = cell;
+    if (c->nlookup == c->caplookup) { c->caplookup = c->caplookup ? c->caplookup * 2 : 1024; c->lookup = (olk_t *)realloc(c->lookup, c->caplookup * sizeof(olk_t)); }
+    c->lookup[c->nlookup].cell = cell; c->lookup[c->nlookup].kind = c->semantic ? 1 : 0; c->nlookup++;
 }
 static void set_selector(octx_t *c, size_t row) {
     if (c->witness_gen_only) return;
@@ -162,8 +164,8 @@ int orc_mock_prover(const octx_t *c, uint64_t *gates, uint64_t *equalities, uint
     }
     for (size_t i = 0; i < c->nceq; i++) { ne++; if (!fr_eq(&c->advice[c->ceq[i].cell], &c->ceq[i].c)) bad++; }
     for (size_t i = 0; i < c->nlookup; i++) {
-        nl++; const ofr_t *v = &c->advice[c->lookup[i]];
-        if (v->l[1] | v->l[2] | v->l[3] || (v->l[0] >> c->lookup_bits)) bad++;
+        nl++; const ofr_t *v = &c->advice[c->lookup[i].cell];
+        if (v->l[1] | v->l[2] | v->l[3] || (v->l[0] >> c->lookup_bits)) { if (c->lookup[i].kind == 1) sf++; else bad++; }
     }
     if (gates) *gates = ng; if (equalities) *equalities = ne; if (lookups) *lookups = nl; if (semantic_failed) *semantic_failed = sf;
     return bad;
@@ -1139,7 +1141,7 @@ int orc_verify_stark(octx_t *c, const oshape_t *s, const oconsts_t *k, const uin
     batches[0].point = chal.stark_zeta;
     { gle_t gv = {{glf_primitive_root_of_unity(s->degree_bits), 0}}; exw_t g = ex_load_constant(c, gv); batches[1].point = ex_mul(c, g, chal.stark_zeta); }
     SC("verify_fri_proof");                                                    /* fri/mod.rs:446-502 */
-    SC("verify_proof_of_work"); orc_range_check(c, chal.fri_pow_response, 64 - s->pow_bits); EC(); /* :130-145 */
+    SC("verify_proof_of_work"); c->semantic++; orc_range_check(c, chal.fri_pow_response, 64 - s->pow_bits); c->semantic--; EC(); /* :130-145 */
     exw_t reduced_openings[2];
     SC("from_os_and_alpha");                                                   /* :45-62 */
     reduced_openings[0] = ex_reduce_with_powers(c, zeta_vals, nz, chal.fri_alpha);

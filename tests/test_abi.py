@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/h2w.h declares; layout queries work without a GPU;
+compute calls fail loudly (no CPU fallback) when no HIP device is visible."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported(h2w):
+    hdr = open(os.path.join(ROOT, "include", "h2w.h")).read()
+    declared = set(re.findall(r"\b(h2w_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"h2w_fr_t", "h2w_assigned_t", "h2w_shape_t", "h2w_poseidon_consts_t"}
+    lib = h2w.lib()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(h2w.SYMBOLS), declared ^ set(h2w.SYMBOLS)
+    assert lib.h2w_abi_version() == 1
+
+
+def test_struct_sizes_match_oracle_side(h2w, oracle):
+    assert C.sizeof(h2w.Shape) == C.sizeof(oracle.Shape) == 64
+    assert C.sizeof(h2w.PoseidonConsts) == C.sizeof(oracle.Consts)
+    assert C.sizeof(h2w.Assigned) == 48
+
+
+@pytest.mark.parametrize("d,q,rb,mode,lb", [(5, 84, 1, 0, 21), (5, 84, 1, 1, 21), (10, 4, 1, 1, 21), (10, 4, 1, 0, 21),
+                                              (16, 28, 2, 1, 21), (20, 28, 1, 1, 21), (10, 4, 1, 1, 13), (10, 3, 1, 0, 8)])
+def test_plan_layout_matches_oracle_cell_count(h2w_api, h2w, oracle, consts, d, q, rb, mode, lb):
+    """Shape compiler (host) vs oracle: same number of advice cells and proof words, incl. other lookup_bits."""
+    ko, kh = consts
+    plan = h2w_api.Plan(h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=mode, lookup_bits=lb), kh)
+    osh = oracle.fibonacci_shape(d, q, rate_bits=rb, hash_mode=mode, lookup_bits=lb)
+    ctx = oracle.Ctx(lb)
+    assert oracle.verify_stark(ctx, osh, ko, oracle.synth_proof(osh, 5)) == 0
+    assert plan.num_cells == ctx.num_cells()
+    assert plan.proof_words == oracle.lib().orc_proof_words(C.byref(osh))
+    plan.close(); ctx.close()
+
+
+def test_eager_cell_counts_without_gpu(h2w_api):
+    """Host bookkeeping of the eager API: cell counts per call need no GPU."""
+    ctx = h2w_api.Context(21)
+    nat = h2w_api.NativeChip(ctx); gl = h2w_api.GoldilocksChip(nat)
+    a = gl.load_constant(5); b = gl.load_constant(7)
+    n0 = ctx.num_cells()
+    c = gl.mul(a, b); assert c.int_value() == 35 and ctx.num_cells() - n0 == 65
+    n0 = ctx.num_cells(); gl.sub(a, b); assert ctx.num_cells() - n0 == 66
+    n0 = ctx.num_cells(); gl.load_witness(9); assert ctx.num_cells() - n0 == 28
+    n0 = ctx.num_cells(); d = gl.div(a, b); assert ctx.num_cells() - n0 == 93 and d.int_value() * 7 % h2w_api.GL_P == 5
+    n0 = ctx.num_cells(); nat.num_to_bits(a, 64); assert ctx.num_cells() - n0 == 446
+    n0 = ctx.num_cells(); nat.select_from_idx([a] * 16, b); assert ctx.num_cells() - n0 == 237
+    n0 = ctx.num_cells(); nat.range_check(a, 48); assert ctx.num_cells() - n0 == 11
+    n0 = ctx.num_cells(); nat.decompose_le(nat.load_witness(1 << 200), 56, 5); assert ctx.num_cells() - n0 == 1 + 68
+    with pytest.raises(h2w_api.H2WError):
+        gl.div(a, gl.load_constant(0))     # reference asserts b != 0 (base.rs:379)
+    ctx.close()
+
+
+def test_no_cpu_fallback(h2w_api, h2w):
+    """Without a HIP device the product refuses to produce cells (it must never route through a CPU path)."""
+    if h2w.lib().h2w_device_count() > 0:
+        pytest.skip("GPU present")
+    ctx = h2w_api.Context(21)
+    h2w_api.GoldilocksChip(h2w_api.NativeChip(ctx)).load_witness(3)
+    with pytest.raises(h2w_api.H2WError, match="no HIP device"):
+        ctx.advice_bytes()
+    ctx.close()

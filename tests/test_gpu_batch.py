@@ -1,0 +1,71 @@
+"""GPU parity, API level 3: h2w_fri_witness_batch (value kernels + expansion kernel on the MI355X) against the CPU
+oracle's advice stream, byte for byte, on the same seeded synthetic proofs.  Small shapes compare every cell of
+every proof; BASELINE.json's configs 1 and 3 (BN254 caps) are compared in full as well (the oracle needs seconds)."""
+import ctypes as C
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1):
+    import torch
+    ko, kh = consts
+    sh = h2w.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc)
+    osh = oracle.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc)
+    plan = h2w_api.Plan(sh, kh)
+    n = len(seeds)
+    proofs = [oracle.synth_proof(osh, s) for s in seeds]
+    host = torch.empty(n * plan.proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda()
+    advice = torch.zeros(n * plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert plan.status(ws.data_ptr(), n, stream) == [0] * n
+    got = advice.cpu().numpy().tobytes()
+    for i, p in enumerate(proofs):
+        ctx = oracle.Ctx(lookup_bits)
+        assert oracle.verify_stark(ctx, osh, ko, p) == 0
+        assert ctx.num_cells() == plan.num_cells
+        want = ctx.advice_bytes()
+        g = got[i * plan.num_cells * 32:(i + 1) * plan.num_cells * 32]
+        if g != want:
+            import numpy as np
+            a = np.frombuffer(g, dtype=np.uint64).reshape(-1, 4); b = np.frombuffer(want, dtype=np.uint64).reshape(-1, 4)
+            bad = np.nonzero((a != b).any(axis=1))[0]
+            raise AssertionError(f"proof {i}: {len(bad)} cells differ, first at {bad[:8]}: got {a[bad[0]]} want {b[bad[0]]}")
+        ctx.close()
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_small_shapes_every_cell(h2w, h2w_api, oracle, consts, mode):
+    run_batch(h2w, h2w_api, oracle, consts, (6, 2, 1, mode), [1, 2, 3])          # no fold step, 2 queries
+    run_batch(h2w, h2w_api, oracle, consts, (7, 3, 2, mode), [4])                # one fold step (the path no reference test exercises)
+    run_batch(h2w, h2w_api, oracle, consts, (5, 1, 1, mode), [5, 6], wlrc=0)     # single query; SVG-era loader
+
+
+@pytest.mark.parametrize("lookup_bits", [13, 8, 17])
+def test_other_lookup_bits(h2w, h2w_api, oracle, consts, lookup_bits):
+    run_batch(h2w, h2w_api, oracle, consts, (7, 2, 1, 1), [7], lookup_bits=lookup_bits)
+    run_batch(h2w, h2w_api, oracle, consts, (6, 1, 1, 0), [8], lookup_bits=lookup_bits)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_config1_full(h2w, h2w_api, oracle, consts, mode):
+    """BASELINE.json configs[0]: 2^10 rows, 4 queries."""
+    run_batch(h2w, h2w_api, oracle, consts, (10, 4, 1, mode), [0xF1B00001, 0xF1B00011])
+
+
+def test_config3_bn254_full(h2w, h2w_api, oracle, consts):
+    """BASELINE.json configs[2]: 2^20 rows, 28 queries, cap_height 4, PoseidonBN254 Merkle — 28.58 M cells, every byte."""
+    run_batch(h2w, h2w_api, oracle, consts, (20, 28, 1, 1), [0xF1B00003])
+
+
+def test_config2_bn254_full(h2w, h2w_api, oracle, consts):
+    """BASELINE.json configs[1]: 2^16 rows, 28 queries, rate_bits 2."""
+    run_batch(h2w, h2w_api, oracle, consts, (16, 28, 2, 1), [0xF1B00002])

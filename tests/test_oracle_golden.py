@@ -1,0 +1,86 @@
+"""Pins the CPU oracle against the only golden data the reference holds for this path: the exact per-call-stack
+advice-cell counts of verifier/profile/{gl,bn254}.svg (extracted by tools/make_golden_svg.py into tests/golden/).
+Shape: Fibonacci STARK n=32 (degree_bits 5), 84 queries, standard_fast_config, lookup_bits 21."""
+import json
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,mode", [("bn254", 1), ("gl", 0)])
+def test_oracle_reproduces_svg_cell_tree(oracle, name, mode):
+    gold = json.load(open(os.path.join(GOLD, f"svg_frames_{name}.json")))
+    k = oracle.synth_consts()
+    # SVG era: witness loading cost 1 cell / element; verify_proof subtree == current source
+    sh = oracle.fibonacci_shape(5, 84, hash_mode=mode, witness_load_range_check=0)
+    pr = oracle.synth_proof(sh, 1234)
+    ctx = oracle.Ctx(21, True, True)
+    assert oracle.verify_stark(ctx, sh, k, pr) == 0, ctx.error()
+    sc = ctx.scopes()
+    assert ctx.num_cells() == gold["total_samples"]
+    bad = [(f["path"], f["cells"], sc.get(f["path"])) for f in gold["frames"] if sc.get(f["path"]) != f["cells"]]
+    assert not bad, bad[:5]
+    assert sc["all;verify_proof"] == {"gl": 93182639, "bn254": 14080080}[name]
+
+
+def test_known_cell_counts_survey_appendix_c(oracle):
+    """Per-op counts at L=21 (validated against the SVGs)."""
+    O = oracle
+    k = O.synth_consts()
+
+    def count(fn):
+        c = O.Ctx(21)
+        fn(c)
+        n = c.num_cells()
+        c.close()
+        return n
+    L = O.lib()
+    a, b, cc = 123456789, 0xFFFFFFFF00000000, 42
+    assert count(lambda c: L.orc_gl_load_witness(c.p, a)) == 28
+    assert count(lambda c: L.orc_gl_mul(c.p, L.orc_gl_load_constant(c.p, a), L.orc_gl_load_constant(c.p, b))) == 2 + 65
+    assert count(lambda c: L.orc_gl_add(c.p, L.orc_gl_load_constant(c.p, a), L.orc_gl_load_constant(c.p, b))) == 2 + 65
+    assert count(lambda c: L.orc_gl_sub(c.p, L.orc_gl_load_constant(c.p, a), L.orc_gl_load_constant(c.p, b))) == 2 + 66
+    assert count(lambda c: L.orc_gl_mul_sub(c.p, L.orc_gl_load_constant(c.p, a), L.orc_gl_load_constant(c.p, cc), L.orc_gl_load_constant(c.p, cc))) == 3 + 70
+    assert count(lambda c: L.orc_gl_div(c.p, L.orc_gl_load_constant(c.p, a), L.orc_gl_load_constant(c.p, b))) == 2 + 93
+    assert count(lambda c: L.orc_gl_inv(c.p, L.orc_gl_load_constant(c.p, a))) == 1 + 94
+
+    def gl_perm(c):
+        st = (O.AV * 12)(*[L.orc_gl_load_constant(c.p, i + 1) for i in range(12)])
+        out = (O.AV * 12)()
+        L.orc_gl_poseidon_permute(c.p, k, st, out)
+    assert count(gl_perm) == 12 + 163478
+
+    def bn_perm(c):
+        st = (O.AV * 4)(*[L.orc_load_constant(c.p, O.Fr.from_int(i + 5)) for i in range(4)])
+        out = (O.AV * 4)()
+        L.orc_bn_poseidon_permute(c.p, k, st, out)
+    assert count(bn_perm) == 4 + 4032 + 1  # + the Context's first (cached) load_zero cell
+
+
+@pytest.mark.parametrize("d,q,rb,mode,expect", [
+    (10, 4, 1, 1, 10796583 + 9132), (10, 4, 1, 0, 27333663 + 9612),
+    (16, 28, 2, 1, 23373701 + 85116), (20, 28, 1, 1, 28469137 + 110752),
+])
+def test_config_totals_match_baseline_md(oracle, d, q, rb, mode, expect):
+    """BASELINE.md §2 work sizes (verify_proof subtree + witness-load cells; BN254 totals +1 cached zero cell)."""
+    sh = oracle.fibonacci_shape(d, q, rate_bits=rb, hash_mode=mode)
+    ctx = oracle.Ctx(21)
+    assert oracle.verify_stark(ctx, sh, oracle.synth_consts(), oracle.synth_proof(sh, 3)) == 0
+    assert ctx.num_cells() == expect + (1 if mode == 1 else 0)
+
+
+def test_mock_prover_holds_on_generated_witness(oracle):
+    """Restated MockProver: every gate a+b*c=d, internal copy/constant equality and lookup
+    holds on the generated witness.  Chip-level assert_equal's of Merkle roots / FRI consistency are counted
+    separately: the synthetic proof is random, i.e. not a valid FRI instance."""
+    for mode in (0, 1):
+        sh = oracle.fibonacci_shape(6, 2, hash_mode=mode)
+        ctx = oracle.Ctx(21, witness_gen_only=False)
+        assert oracle.verify_stark(ctx, sh, oracle.synth_consts(), oracle.synth_proof(sh, 99)) == 0
+        r = ctx.mock_prover()
+        assert r["bad"] == 0, r
+        assert r["gates"] > 0 and r["equalities"] > 0 and r["lookups"] > 0
+        assert r["semantic_failed"] > 0
+        ctx.close()
