@@ -130,6 +130,26 @@ class H2WError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64.so (soname
+    libamdhip64.so.7, same as /opt/rocm's); if libh2w.so pulled in /opt/rocm's copy first, a later `import torch`
+    would bring a second runtime and neither would see the GPU.  So when torch is installed, map its copy first:
+    libh2w.so's DT_NEEDED libamdhip64.so.7 then binds to it by soname, and device pointers / streams are shared."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libh2w.so (built in-tree by build.sh / __graft_entry__.build()).  Fails loudly if absent."""
     global _lib
@@ -137,6 +157,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise H2WError(f"{LIB_PATH} not found: build the HIP extension first (./build.sh). There is no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
