@@ -184,6 +184,13 @@ class Plan:
         _ck(self.L.h2w_plan_status(self.p, workspace_ptr, n, st, stream), "h2w_plan_status")
         return list(st)
 
+    def timing(self, back=0):
+        """(value-pass ms, expansion-kernel ms, total ms) of the batch call `back` calls before the last, from HIP
+        events recorded on the call's stream."""
+        ms = (C.c_float * 3)()
+        _ck(self.L.h2w_plan_timing(self.p, back, ms), "h2w_plan_timing")
+        return tuple(ms)
+
     def last_timing(self):
         ms = (C.c_float * 3)()
         _ck(self.L.h2w_plan_last_timing(self.p, ms), "h2w_plan_last_timing")

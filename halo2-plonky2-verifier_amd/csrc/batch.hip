@@ -116,7 +116,8 @@ struct h2w_plan {
     Derived d; ProofLayout pl;
     uint64_t nrec = 0, ncells = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
-    hipEvent_t ev[3]; bool ev_ready = false, ev_recorded = false;
+    static constexpr int EV_RING = 64;
+    hipEvent_t evr[EV_RING][3]; hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
 };
 
@@ -177,7 +178,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         H2W_HIP(hipMemcpy(pl->d_ncells, nc.data(), nc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         H2W_HIP(hipMalloc((void **)&pl->d_inv, inv.size() * sizeof(fr_t)));
         H2W_HIP(hipMemcpy(pl->d_inv, inv.data(), inv.size() * sizeof(fr_t), hipMemcpyHostToDevice));
-        for (int i = 0; i < 3; i++) H2W_HIP(hipEventCreate(&pl->ev[i]));
+        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 3; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
         pl->ev_ready = true;
         return 0;
     };
@@ -190,7 +191,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
-    if (p->ev_ready) for (int i = 0; i < 3; i++) (void)hipEventDestroy(p->ev[i]);
+    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 3; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
     delete p;
 }
@@ -222,6 +223,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = p->ncells;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
+    p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
     H2W_HIP(hipEventRecord(p->ev[0], stream));
     hipLaunchKernelGGL(k_prologue, dim3((unsigned)((n_proofs + 63) / 64)), dim3(64), 0, stream, A);
     const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
@@ -252,6 +254,15 @@ int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest
     H2W_HIP(hipMemsetAsync(digest4_dev, 0, 32, stream));
     if (n_cells) hipLaunchKernelGGL(k_digest, dim3(2048), dim3(256), 0, stream, (const ulonglong4 *)advice_dev, n_cells, (unsigned long long *)digest4_dev);
     H2W_HIP(hipGetLastError());
+    return 0;
+}
+int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[3]) {   // `back` batches before the last one (ring of 64)
+    if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing: no such batch"); return -1; }
+    hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
+    H2W_HIP(hipEventSynchronize(ev[2]));
+    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+    H2W_HIP(hipEventElapsedTime(&ms[2], ev[0], ev[2]));
     return 0;
 }
 int h2w_plan_last_timing(h2w_plan *p, float ms[3]) {

@@ -154,6 +154,8 @@ int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest
 /* Timing of the last batch call's kernels in ms via HIP events recorded on `stream`
  * (index: 0 = value pass, 1 = expansion, 2 = total).  Blocks until the batch finished. */
 int h2w_plan_last_timing(h2w_plan *, float ms[3]);
+/* Same for the batch `back` calls before the last one (a ring of the last 64 batch calls is kept). */
+int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[3]);
 
 #ifdef __cplusplus
 }
