@@ -161,6 +161,7 @@ class Plan:
         self.num_cells = int(self.L.h2w_plan_num_cells(self.p))
         self.proof_words = int(self.L.h2w_plan_proof_words(self.p))
         self.num_records = int(self.L.h2w_plan_num_records(self.p))
+        self.num_record_cells = int(self.L.h2w_plan_num_record_cells(self.p))
 
     def close(self):
         if getattr(self, "p", None):
@@ -185,13 +186,13 @@ class Plan:
         return list(st)
 
     def timing(self, back=0):
-        """(value-pass ms, expansion-kernel ms, total ms) of the batch call `back` calls before the last, from HIP
-        events recorded on the call's stream."""
-        ms = (C.c_float * 3)()
+        """(prologue ms, strands ms, expansion-kernel ms, total ms) of the batch call `back` calls before the last,
+        from HIP events recorded on the call's stream."""
+        ms = (C.c_float * 4)()
         _ck(self.L.h2w_plan_timing(self.p, back, ms), "h2w_plan_timing")
         return tuple(ms)
 
     def last_timing(self):
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         _ck(self.L.h2w_plan_last_timing(self.p, ms), "h2w_plan_last_timing")
         return tuple(ms)

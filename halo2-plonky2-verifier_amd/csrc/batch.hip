@@ -14,27 +14,34 @@
 #include <cstring>
 #include "common.h"
 #include "valbackend.h"
+#include "coop.h"
 
 namespace h2w {
 
 typedef ValBackend<DevSink> DevB;
 typedef ChallengeBlock<DevB> DevCB;
+typedef ValBackend<CoopSink> CoopB;   // same wire types as DevB: ChallengeBlock layouts coincide
 
 struct PlanSink {
+    static constexpr bool kCoop = false;
+    void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     std::vector<uint64_t> *meta; const TemplateTable *tt; StrandTable *st;
     uint64_t nrec = 0, cell_off = 0, cur_q_rec = 0, cur_q_cell = 0, mk_rec0 = 0, mk_cell0 = 0; bool mk_zc = false;
+    std::vector<uint64_t> *unit_cell = nullptr; uint64_t nunit = 0, cur_q_unit = 0, mk_unit0 = 0; bool pu_zc = false;
+    void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
+    void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
     void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta->push_back(meta_pack((uint32_t)t, cell_off)); nrec++; cell_off += (uint64_t)tt->ncells(t); }
     void cell(const fr_t &) { cell_off++; }
     void skip(uint64_t, uint64_t) {}
-    void merkle_begin(int, int, bool zc) { mk_rec0 = nrec; mk_cell0 = cell_off; mk_zc = zc; }
+    void merkle_begin(int, int, bool zc, uint64_t) { mk_rec0 = nrec; mk_cell0 = cell_off; mk_zc = zc; mk_unit0 = nunit; }
     void merkle_end(int q, int kind, bool zc) {
         if (q > 1) return;
         st->mk_rec_rel[q][kind] = mk_rec0 - cur_q_rec; st->mk_cell_rel[q][kind] = mk_cell0 - cur_q_cell;
-        st->mk_nrec[q][kind] = nrec - mk_rec0; st->mk_ncell[q][kind] = cell_off - mk_cell0;
+        st->mk_nrec[q][kind] = nrec - mk_rec0; st->mk_ncell[q][kind] = cell_off - mk_cell0; st->mk_unit_rel[q][kind] = mk_unit0 - cur_q_unit;
         if (!mk_zc && zc) st->first_zero_kind = (q == 0) ? kind : -2;
     }
-    void query_begin(int q) { cur_q_rec = nrec; cur_q_cell = cell_off; if (q <= 1) { st->q_rec0[q] = nrec; st->q_cell0[q] = cell_off; } }
-    void query_end(int q) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; } }
+    void query_begin(int q, uint64_t) { cur_q_rec = nrec; cur_q_cell = cell_off; cur_q_unit = nunit; if (q <= 1) { st->q_rec0[q] = nrec; st->q_cell0[q] = cell_off; st->q_unit0[q] = nunit; } }
+    void query_end(int q, uint64_t) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; st->q_nunit[q] = nunit - cur_q_unit; } }
 };
 
 struct BatchArgs {
@@ -46,11 +53,13 @@ struct BatchArgs {
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
     StrandTable st; FrParams P;
     int nproofs;
+    fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
 };
 
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
     c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = &A.st; c.split = true;
+    c.split_bn = false; c.units = A.units + (uint64_t)p * A.unit_stride * 4; c.consts_mont = A.consts_mont; c.bn_perm_cells = A.bn_perm_cells;
     return c;
 }
 
@@ -62,6 +71,36 @@ __global__ __launch_bounds__(64) void k_prologue(BatchArgs A) {
     Verifier<DevB> V(be, A.shape, A.consts);
     V.prologue(A.cbs[p]);
     A.status[p] = be.status;
+}
+
+// one wavefront per proof: wave-uniform gadget code, Goldilocks Poseidon split over 12 lanes (coop.h)
+__global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
+    const int p = blockIdx.x;
+    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    CoopB be(sink, make_cfg(A, p), true);
+    Verifier<CoopB> V(be, A.shape, A.consts);
+    V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
+    if (threadIdx.x == 0) A.status[p] = be.status;
+}
+
+// Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot
+__global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
+    const int idx = blockIdx.x, nq = A.shape.num_queries;
+    const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
+    CoopB be(sink, make_cfg(A, p), true);
+    Verifier<CoopB> V(be, A.shape, A.consts);
+    const uint64_t x = A.cbs[p].fri_query_indices[q];
+    const int lde = V.d.lde_bits; int lo = 0;
+    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
+    uint64_t bits[64]; const int nb = lde - lo;
+    for (int i = 0; i < nb; i++) bits[i] = (x >> (lo + i)) & 1;
+    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
+    V.merkle_strand(q, kind, bits, nb, cap_index);
+    if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
 // blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
@@ -83,7 +122,9 @@ __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
     }
     const int kind = role <= n_or ? role - 1 : 3 + (role - 1 - n_or);   // roles 1..n_or: initial oracles; then fold steps
     sink.nrec += A.st.mk_rec_rel[sq][kind]; sink.cell_off += A.st.mk_cell_rel[sq][kind];
-    DevB be(sink, make_cfg(A, p), !(q == 0 && kind == A.st.first_zero_kind));
+    ValCfg mc = make_cfg(A, p); mc.split_bn = true;
+    DevB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
+    be.unit_idx = strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind];
     Verifier<DevB> V(be, A.shape, A.consts);
     // index bits of this strand (fri/mod.rs:363-369, 407-408), from the query-index challenge value
     const uint64_t x = cb.fri_query_indices[q];
@@ -94,6 +135,21 @@ __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
     const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
     V.merkle_strand(q, kind, bits, nb, cap_index);
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+
+// PoseidonBN254 permutation units: one lane per permutation (all independent once the chain strands have stored
+// their input states); runs the chip code of hash/poseidon_bn254/permutation.rs:190-203 and writes its 4,032 cells.
+__global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nu = A.st.total_unit;
+    if (idx >= nu * (uint64_t)A.nproofs) return;
+    const int p = (int)(idx / nu); const uint64_t u = idx % nu;
+    DevSink sink; sink.recs = nullptr; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = A.unit_cell[u]; sink.ncells = A.ncells;
+    DevB be(sink, make_cfg(A, p), (int64_t)u != A.st.first_zero_unit);
+    PoseidonBN254PermutationChip<DevB> pb(be, A.consts);
+    fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
+    for (int i = 0; i < 4; i++) st[i] = in[i];
+    pb.permute(st);
 }
 
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
@@ -114,10 +170,11 @@ struct h2w_plan {
     h2w_shape_t shape; int device;
     TemplateTable tt; DeviceTables dt; StrandTable st; FrParams P;
     Derived d; ProofLayout pl;
-    uint64_t nrec = 0, ncells = 0;
+    uint64_t nrec = 0, ncells = 0, rec_cells = 0;
+    uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
-    hipEvent_t evr[EV_RING][3]; hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
+    hipEvent_t evr[EV_RING][4]; hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
 };
 
@@ -137,24 +194,28 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     pl->shape = s; pl->device = device_id; pl->P = fr_params_init();
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
     if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
-    memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1;
+    memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1; pl->st.first_zero_unit = -1;
+    std::vector<uint64_t> unit_cell;
     // host inverse table
     std::vector<fr_t> inv(2 * INV_TAB, fr_zero());
     for (int k2 = 1; k2 < INV_TAB; k2++) { inv[k2] = fr_inv(fr_from_u64((uint64_t)k2), pl->P); inv[INV_TAB + k2] = fr_neg(inv[k2]); }
     // shape compile: sequential replay with the counting sink on an all-zero proof
     std::vector<uint64_t> meta; std::vector<uint64_t> zero_proof(pl->pl.total, 0);
     {
-        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st;
+        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st; sink.unit_cell = &unit_cell;
         ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = s.hash_mode; cfg.L = s.lookup_bits; cfg.P = pl->P;
-        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false;
+        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.units = nullptr; cfg.consts_mont = nullptr; cfg.bn_perm_cells = 0;
         ValBackend<PlanSink> be(sink, cfg, false);
         Verifier<ValBackend<PlanSink>> V(be, pl->shape, consts);
         ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
         V.run_all(*cb);
         delete cb;
-        pl->nrec = sink.nrec; pl->ncells = sink.cell_off;
+        pl->nrec = sink.nrec; pl->ncells = sink.cell_off; pl->nunit = sink.nunit; pl->st.total_unit = sink.nunit;
+        for (uint64_t m : meta) pl->rec_cells += (uint64_t)pl->tt.ncells((int)meta_tmpl(m));
         pl->st.pro_nrec = pl->st.q_rec0[0]; pl->st.pro_ncell = pl->st.q_cell0[0]; pl->st.total_rec = sink.nrec; pl->st.total_cell = sink.cell_off;
         if (s.num_queries == 1) {
+            pl->st.q_unit0[1] = pl->st.q_unit0[0]; pl->st.q_nunit[1] = pl->st.q_nunit[0];
+            for (int k2 = 0; k2 < MK_KINDS; k2++) pl->st.mk_unit_rel[1][k2] = pl->st.mk_unit_rel[0][k2];
             pl->st.q_rec0[1] = pl->st.q_rec0[0]; pl->st.q_cell0[1] = pl->st.q_cell0[0]; pl->st.q_nrec[1] = pl->st.q_nrec[0]; pl->st.q_ncell[1] = pl->st.q_ncell[0];
             for (int k2 = 0; k2 < MK_KINDS; k2++) { pl->st.mk_rec_rel[1][k2] = pl->st.mk_rec_rel[0][k2]; pl->st.mk_cell_rel[1][k2] = pl->st.mk_cell_rel[0][k2]; pl->st.mk_nrec[1][k2] = pl->st.mk_nrec[0][k2]; pl->st.mk_ncell[1][k2] = pl->st.mk_ncell[0][k2]; }
         }
@@ -171,6 +232,20 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         if (pl->dt.upload(pl->tt) != 0) return -1;
         H2W_HIP(hipMalloc((void **)&pl->d_meta, meta.size() * sizeof(uint64_t)));
         H2W_HIP(hipMemcpy(pl->d_meta, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (!unit_cell.empty()) {
+            H2W_HIP(hipMalloc((void **)&pl->d_unit_cell, unit_cell.size() * sizeof(uint64_t)));
+            H2W_HIP(hipMemcpy(pl->d_unit_cell, unit_cell.data(), unit_cell.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        }
+        {   // constants in Montgomery form for the value-domain BN254 Poseidon
+            h2w_poseidon_consts_t *km = new h2w_poseidon_consts_t(*consts);
+            for (int i = 0; i < 88; i++) km->bn_c[i] = fr_mont_mul(consts->bn_c[i], pl->P.r2, pl->P.ninv);
+            for (int i = 0; i < 392; i++) km->bn_s[i] = fr_mont_mul(consts->bn_s[i], pl->P.r2, pl->P.ninv);
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { km->bn_m[i][j] = fr_mont_mul(consts->bn_m[i][j], pl->P.r2, pl->P.ninv); km->bn_p[i][j] = fr_mont_mul(consts->bn_p[i][j], pl->P.r2, pl->P.ninv); }
+            hipError_t e1 = hipMalloc((void **)&pl->d_consts_mont, sizeof(h2w_poseidon_consts_t));
+            hipError_t e2 = e1 == hipSuccess ? hipMemcpy(pl->d_consts_mont, km, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice) : e1;
+            delete km;
+            H2W_HIP(e2);
+        }
         H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t)));
         H2W_HIP(hipMemcpy(pl->d_consts, consts, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
         std::vector<uint16_t> nc(T_MAX, 0); for (size_t i = 0; i < pl->tt.info.size(); i++) nc[i] = pl->tt.info[i].ncells;
@@ -178,7 +253,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         H2W_HIP(hipMemcpy(pl->d_ncells, nc.data(), nc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         H2W_HIP(hipMalloc((void **)&pl->d_inv, inv.size() * sizeof(fr_t)));
         H2W_HIP(hipMemcpy(pl->d_inv, inv.data(), inv.size() * sizeof(fr_t), hipMemcpyHostToDevice));
-        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 3; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
+        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 4; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
         pl->ev_ready = true;
         return 0;
     };
@@ -188,26 +263,30 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
 void h2w_plan_free(h2w_plan *p) {
     if (!p) return;
     if (p->d_meta) (void)hipFree(p->d_meta);
+    if (p->d_unit_cell) (void)hipFree(p->d_unit_cell);
+    if (p->d_consts_mont) (void)hipFree(p->d_consts_mont);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
-    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 3; i++) (void)hipEventDestroy(p->evr[r][i]);
+    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 4; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
     delete p;
 }
 uint64_t h2w_plan_num_cells(const h2w_plan *p) { return p ? p->ncells : 0; }
 uint64_t h2w_plan_proof_words(const h2w_plan *p) { return p ? p->pl.total : 0; }
 uint64_t h2w_plan_num_records(const h2w_plan *p) { return p ? p->nrec : 0; }
-static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_cbs, size_t &o_status, size_t &total) {
+uint64_t h2w_plan_num_record_cells(const h2w_plan *p) { return p ? p->rec_cells : 0; }
+static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_cbs, size_t &o_status, size_t &o_units, size_t &total) {
     size_t o = 0;
     o_recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
     o_cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
     o_status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
+    o_units = o; o += align_up((size_t)n * p->nunit * 4 * sizeof(fr_t), 256);
     total = o;
 }
 uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
     if (!p) return 0;
-    size_t a, b, c, t; ws_layout(p, n_proofs, a, b, c, t); return t;
+    size_t a, b, c, d2, t; ws_layout(p, n_proofs, a, b, c, d2, t); return t;
 }
 int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
     if (!p) { set_error("h2w_fri_witness_batch: null plan"); return -1; }
@@ -216,19 +295,29 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     if (n_proofs == 0) return 0;
     if (n_proofs * (uint64_t)p->shape.num_queries > 0x7fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
     hipStream_t stream = (hipStream_t)stream_;
-    size_t o_recs, o_cbs, o_status, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, total);
+    size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
     char *ws = (char *)workspace_dev;
     BatchArgs A;
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
     A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = p->ncells;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
+    A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
+    A.bn_perm_cells = 4032;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
     H2W_HIP(hipEventRecord(p->ev[0], stream));
-    hipLaunchKernelGGL(k_prologue, dim3((unsigned)((n_proofs + 63) / 64)), dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(k_prologue_coop, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
+    H2W_HIP(hipEventRecord(p->ev[3], stream));
     const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
     // roles: 0 = query glue, then one role per merkle strand kind (initial oracles, fold steps)
-    hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+    if (p->shape.hash_mode == 0) {   // Goldilocks-Poseidon Merkle: glue lanes + one cooperating wavefront per Merkle strand
+        hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+        hipLaunchKernelGGL(k_merkle_gl_coop, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+    } else {
+        hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+        const uint64_t nunits = p->nunit * n_proofs;
+        if (nunits) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nunits + 63) / 64)), dim3(64), 0, stream, A);
+    }
     H2W_HIP(hipEventRecord(p->ev[1], stream));
     ExpandArgs E;
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
@@ -242,7 +331,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
 }
 int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {
     if (!p || !workspace_dev || !host_status) { set_error("h2w_plan_status: null argument"); return -1; }
-    size_t o_recs, o_cbs, o_status, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, total);
+    size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
     hipStream_t stream = (hipStream_t)stream_;
     H2W_HIP(hipMemcpyAsync(host_status, (const char *)workspace_dev + o_status, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     H2W_HIP(hipStreamSynchronize(stream));
@@ -256,22 +345,16 @@ int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest
     H2W_HIP(hipGetLastError());
     return 0;
 }
-int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[3]) {   // `back` batches before the last one (ring of 64)
+int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[4]) {   // `back` batches before the last one (ring of 64)
     if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing: no such batch"); return -1; }
     hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
     H2W_HIP(hipEventSynchronize(ev[2]));
-    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    H2W_HIP(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
-    H2W_HIP(hipEventElapsedTime(&ms[2], ev[0], ev[2]));
+    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[3]));   // prologue strands
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[3], ev[1]));   // query + merkle strands
+    H2W_HIP(hipEventElapsedTime(&ms[2], ev[1], ev[2]));   // expansion kernel
+    H2W_HIP(hipEventElapsedTime(&ms[3], ev[0], ev[2]));   // whole batch
     return 0;
 }
-int h2w_plan_last_timing(h2w_plan *p, float ms[3]) {
-    if (!p || !p->ev_recorded) { set_error("h2w_plan_last_timing: no batch recorded"); return -1; }
-    H2W_HIP(hipEventSynchronize(p->ev[2]));
-    H2W_HIP(hipEventElapsedTime(&ms[0], p->ev[0], p->ev[1]));
-    H2W_HIP(hipEventElapsedTime(&ms[1], p->ev[1], p->ev[2]));
-    H2W_HIP(hipEventElapsedTime(&ms[2], p->ev[0], p->ev[2]));
-    return 0;
-}
+int h2w_plan_last_timing(h2w_plan *p, float ms[4]) { return h2w_plan_timing(p, 0, ms); }
 
 }  // extern "C"

@@ -235,7 +235,10 @@ template <class B> struct PoseidonPermutationChip {
         for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) { constant_layer(st, round_ctr); sbox_layer(st); mds_layer(st); round_ctr += 1; }
     }
     HF void load_zero(Gl *st) { gl.load_zero_array(SPONGE_WIDTH, st); }               // :264-268
-    HNI void permute(Gl *st) { int rc = 0; full_rounds(st, rc); partial_rounds(st, rc); full_rounds(st, rc); } // :270-284
+    HNI void permute(Gl *st) {                                                        // :270-284
+        if constexpr (B::kCoopPoseidon) be.coop_poseidon_permute(st, k);              // one wavefront cooperates on the 12-wide state (coop.h)
+        else { int rc = 0; full_rounds(st, rc); partial_rounds(st, rc); full_rounds(st, rc); }
+    }
     HF void absorb_goldilocks(Gl *st, const Gl *in, int n) {                          // :286-301 (overwrite mode)
         for (int off = 0; off < n; off += SPONGE_RATE) {
             int len = n - off < SPONGE_RATE ? n - off : SPONGE_RATE;
@@ -284,7 +287,12 @@ template <class B> struct PoseidonBN254PermutationChip {
         exp5_state(st);
         if (is_first) { ark(st, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(st, p); } else mix(st, m);
     }
-    HF void permute(Fr *st) { ark(st, 0); full_rounds(st, true); partial_rounds(st); full_rounds(st, false); }   // :190-203
+    HF void permute(Fr *st) {                                                                         // :190-203
+        if (be.bn_perm_unit(st, k)) return;     // device chain strands: only the output state is needed here; the 4,032 cells are emitted by the unit kernel
+        be.bn_perm_begin();
+        ark(st, 0); full_rounds(st, true); partial_rounds(st); full_rounds(st, false);
+        be.bn_perm_end();
+    }
     HF void absorb_goldilocks(Fr *st, const Gl *in, int n) {                                          // :205-228
         for (int off = 0; off < n; off += BN_RATE * 3) {
             int len = n - off < BN_RATE * 3 ? n - off : BN_RATE * 3;
@@ -293,6 +301,34 @@ template <class B> struct PoseidonBN254PermutationChip {
         }
     }
 };
+
+// value-domain BN254 Poseidon (same schedule as the chip above), Montgomery form throughout: used by the Merkle
+// chain strands, which only need each permutation's OUTPUT state.  `km` holds the constants in Montgomery form.
+HNI inline void bn_poseidon_native(fr_t *st /*canonical in/out*/, const h2w_poseidon_consts_t *km, const FrParams &P) {
+    fr_t s[BN_WIDTH];
+    for (int i = 0; i < BN_WIDTH; i++) s[i] = fr_mont_mul(st[i], P.r2, P.ninv);
+    auto exp5 = [&](const fr_t &x) { fr_t x2 = fr_mont_mul(x, x, P.ninv), x4 = fr_mont_mul(x2, x2, P.ninv); return fr_mont_mul(x4, x, P.ninv); };
+    auto ark = [&](int it) { for (int i = 0; i < BN_WIDTH; i++) s[i] = fr_add(s[i], km->bn_c[it + i]); };
+    auto mix = [&](const h2w_fr_t (*m)[4]) {
+        fr_t ns[BN_WIDTH];
+        for (int i = 0; i < BN_WIDTH; i++) { ns[i] = fr_zero(); for (int j = 0; j < BN_WIDTH; j++) ns[i] = fr_add(ns[i], fr_mont_mul(m[j][i], s[j], P.ninv)); }
+        for (int i = 0; i < BN_WIDTH; i++) s[i] = ns[i];
+    };
+    ark(0);
+    for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); ark((r + 1) * BN_WIDTH); mix(km->bn_m); }
+    for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(km->bn_p);
+    for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+        s[0] = fr_add(exp5(s[0]), km->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]);
+        fr_t ns0 = fr_zero();
+        for (int j = 0; j < BN_WIDTH; j++) ns0 = fr_add(ns0, fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + j], s[j], P.ninv));
+        for (int kk = 1; kk < BN_WIDTH; kk++) s[kk] = fr_add(s[kk], fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1], s[0], P.ninv));
+        s[0] = ns0;
+    }
+    for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); ark((BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH); mix(km->bn_m); }
+    for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); mix(km->bn_m);
+    fr_t one = fr_from_u64(1);
+    for (int i = 0; i < BN_WIDTH; i++) st[i] = fr_mont_mul(s[i], one, P.ninv);
+}
 
 // =========================================================================== HasherChip (hash/mod.rs:52-127; hash/poseidon/hash.rs; hash/poseidon_bn254/hash.rs)
 template <class B> struct HashW { typename B::Gl e[4]; typename B::Fr f; };   // PoseidonHashWire (e) / PoseidonBN254HashWire (f)

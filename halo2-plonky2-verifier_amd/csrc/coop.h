@@ -1,0 +1,128 @@
+// coop.h — wavefront-cooperative value kernels (device only).
+//
+// CoopSink: one 64-lane wavefront executes one strand of verifier.h *wave-uniformly* (every lane runs the same
+// gadget code on the same values; lane 0 alone writes records / direct cells), and the lanes split up the one
+// wide thing in it: the Goldilocks Poseidon permutation (hash/poseidon/permutation.rs:43-284), 12 lanes = the 12
+// state elements / MDS rows, state exchanged through LDS.  It emits exactly the 2,604 records the sequential
+// template code (chips.h PoseidonPermutationChip) emits, at the same indices — tests/test_gpu_batch.py compares
+// the resulting advice with the oracle byte for byte.
+#pragma once
+#include "valbackend.h"
+
+namespace h2w {
+
+constexpr int GLP_RECS_FULL = 12 + 48 + 1 + 12 * 14;           // constant_layer, sbox_layer, mds_layer
+constexpr int GLP_RECS_PARTIAL_ROUND = 4 + 1 + 1 + 11 + 1 + 11; // sbox, +const, d = m00*s0, d chain, zeros, v row
+constexpr int GLP_RECS_PARTIAL = 12 + 1 + 121 + N_PARTIAL_ROUNDS * GLP_RECS_PARTIAL_ROUND;
+constexpr int GLP_RECS = 2 * HALF_N_FULL_ROUNDS * GLP_RECS_FULL + GLP_RECS_PARTIAL;   // 2604
+
+struct CoopSink {
+    static constexpr bool kCoop = true;
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane;
+    __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+        if (lane == 0) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec] = r; }
+        nrec++; cell_off += ncells[t];
+    }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (lane == 0) out[cell_off] = v; cell_off++; }
+    __device__ __forceinline__ void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
+    __device__ void merkle_begin(int, int, bool, uint64_t) {}
+    __device__ void merkle_end(int, int, bool) {}
+    __device__ void query_begin(int, uint64_t) {}
+    __device__ void query_end(int, uint64_t) {}
+    __device__ void bn_perm_begin(bool) {}
+    __device__ void bn_perm_end(bool) {}
+
+    __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *k) {
+        __shared__ uint64_t s_a[SPONGE_WIDTH], s_b[SPONGE_WIDTH];
+        rec_t *R = recs + nrec;
+        const int l = lane;
+        auto W = [&](int idx, uint64_t A, uint64_t B, uint64_t C) { rec_t r; r.a = A; r.b = B; r.c = C; r.d = 0; R[idx] = r; };
+        if (l < SPONGE_WIDTH) s_a[l] = st[l];
+        __syncthreads();
+        int base = 0, round_ctr = 0;
+        auto full_round = [&]() {
+            if (l < SPONGE_WIDTH) {
+                uint64_t x = s_a[l]; const uint64_t rc = k->all_round_constants[l + SPONGE_WIDTH * round_ctr];
+                W(base + l, rc, 1, x); x = gl_add(x, rc);                                   // constant_layer
+                const int sb = base + 12 + 4 * l;                                            // sbox_monomial: x^7
+                const uint64_t x2 = gl_mul(x, x); W(sb, x, x, 0);
+                const uint64_t x4 = gl_mul(x2, x2); W(sb + 1, x2, x2, 0);
+                const uint64_t x6 = gl_mul(x4, x2); W(sb + 2, x4, x2, 0);
+                const uint64_t x7 = gl_mul(x6, x); W(sb + 3, x6, x, 0);
+                s_b[l] = x7;
+            }
+            __syncthreads();
+            const int mb = base + 60;                                                        // mds_layer
+            if (l == 0) W(mb, 0, 0, 0);
+            if (l < SPONGE_WIDTH) {
+                const int rb = mb + 1 + 14 * l; W(rb, 0, 0, 0);
+                uint64_t res = 0;
+                for (int i = 0; i < SPONGE_WIDTH; i++) {
+                    const uint64_t c = k->mds_circ[i], v = s_b[(i + l) % SPONGE_WIDTH];
+                    W(rb + 1 + i, c, v, res); res = gl_muladd(c, v, res);
+                }
+                const uint64_t c = k->mds_diag[l], v = s_b[l];
+                W(rb + 13, c, v, res); res = gl_muladd(c, v, res);
+                s_a[l] = res;
+            }
+            __syncthreads();
+            base += GLP_RECS_FULL; round_ctr++;
+        };
+        for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round();
+        // ---- partial rounds (hash/poseidon/permutation.rs:216-239)
+        if (l < SPONGE_WIDTH) {                                                              // partial_first_constant_layer
+            const uint64_t x = s_a[l], c = k->fast_partial_first_round_constant[l];
+            W(base + l, c, 1, x); s_b[l] = gl_add(x, c);
+        }
+        __syncthreads();
+        base += 12;
+        if (l == 0) { W(base, 0, 0, 0); s_a[0] = s_b[0]; }                                   // mds_partial_layer_init
+        else if (l < SPONGE_WIDTH) {
+            uint64_t res = 0;
+            for (int r = 1; r < SPONGE_WIDTH; r++) {
+                const uint64_t t = k->fast_partial_round_initial_matrix[r - 1][l - 1], v = s_b[r];
+                W(base + 1 + (r - 1) * 11 + (l - 1), t, v, res); res = gl_muladd(t, v, res);
+            }
+            s_a[l] = res;
+        }
+        __syncthreads();
+        base += 122;
+        for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
+            if (l == 0) {
+                const uint64_t x = s_a[0];
+                const uint64_t x2 = gl_mul(x, x); W(base, x, x, 0);
+                const uint64_t x4 = gl_mul(x2, x2); W(base + 1, x2, x2, 0);
+                const uint64_t x6 = gl_mul(x4, x2); W(base + 2, x4, x2, 0);
+                const uint64_t x7 = gl_mul(x6, x); W(base + 3, x6, x, 0);
+                const uint64_t c = k->fast_partial_round_constants[r];
+                W(base + 4, c, 1, x7); s_a[0] = gl_add(x7, c);
+            }
+            __syncthreads();
+            const uint64_t s0 = s_a[0];                                                      // mds_partial_layer_fast
+            if (l == 0) {
+                const uint64_t m00 = k->mds_circ[0] + k->mds_diag[0];
+                W(base + 5, m00, s0, 0); uint64_t d = gl_mul(m00, s0);
+                for (int i = 1; i < SPONGE_WIDTH; i++) { const uint64_t t = k->fast_partial_round_w_hats[r][i - 1], v = s_a[i]; W(base + 5 + i, t, v, d); d = gl_muladd(t, v, d); }
+                W(base + 17, 0, 0, 0);
+                s_b[0] = d;
+            } else if (l < SPONGE_WIDTH) {
+                const uint64_t t = k->fast_partial_round_vs[r][l - 1], v = s_a[l];
+                W(base + 17 + l, t, s0, v); s_b[l] = gl_muladd(t, s0, v);
+            }
+            __syncthreads();
+            if (l < SPONGE_WIDTH) s_a[l] = s_b[l];
+            __syncthreads();
+            base += GLP_RECS_PARTIAL_ROUND;
+        }
+        round_ctr += N_PARTIAL_ROUNDS;
+        for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round();
+        for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = s_a[i];
+        __syncthreads();
+        const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
+        const uint64_t full_cells = 12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA);
+        const uint64_t part_cells = 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
+        nrec += GLP_RECS; cell_off += 2 * HALF_N_FULL_ROUNDS * full_cells + part_cells;
+    }
+};
+
+}  // namespace h2w

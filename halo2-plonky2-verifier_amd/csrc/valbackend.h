@@ -20,7 +20,10 @@ struct StrandTable {
     uint64_t mk_rec_rel[2][MK_KINDS], mk_cell_rel[2][MK_KINDS], mk_nrec[2][MK_KINDS], mk_ncell[2][MK_KINDS];
     int first_zero_kind;     // merkle kind (of query 0) that emits the Context's first load_zero cell; -1 = none
     uint64_t pro_nrec, pro_ncell, total_rec, total_cell;
+    // BN254 permutation units (one unit = the 4,032(+1) cells of one PoseidonBN254 permute call)
+    uint64_t q_unit0[2], q_nunit[2], mk_unit_rel[2][MK_KINDS], total_unit; int64_t first_zero_unit;
 };
+HF uint64_t strand_q_unit(const StrandTable &t, int q) { return q == 0 ? t.q_unit0[0] : t.q_unit0[1] + (uint64_t)(q - 1) * t.q_nunit[1]; }
 HF uint64_t strand_q_rec(const StrandTable &t, int q) { return q == 0 ? t.q_rec0[0] : t.q_rec0[1] + (uint64_t)(q - 1) * t.q_nrec[1]; }
 HF uint64_t strand_q_cell(const StrandTable &t, int q) { return q == 0 ? t.q_cell0[0] : t.q_cell0[1] + (uint64_t)(q - 1) * t.q_ncell[1]; }
 
@@ -31,11 +34,17 @@ struct ValCfg {
     const fr_t *inv_pos, *inv_neg;   // inverses of +-k, k < INV_TAB (Assigned::Rational(1,x) cells of is_zero)
     const StrandTable *st;           // null on the sequential (plan) run
     bool split;                      // true: merkle calls are skipped (their cells belong to merkle strands)
+    bool split_bn;                   // true: BN254 permutations are recorded as units (input state) and evaluated natively
+    fr_t *units;                     // this proof's unit inputs [n_units][4] (split_bn)
+    const h2w_poseidon_consts_t *consts_mont;   // constants in Montgomery form (split_bn)
+    uint64_t bn_perm_cells;          // cells of one permute call (4032)
 };
 
 template <class Sink> struct ValBackend {
     typedef uint64_t Gl; typedef uint64_t Bool; typedef fr_t Fr; typedef u128 Big;
-    Sink &sink; ValCfg cfg; bool zero_cached; uint32_t status;
+    static constexpr bool kCoopPoseidon = Sink::kCoop;
+    Sink &sink; ValCfg cfg; bool zero_cached; uint32_t status; uint64_t unit_idx = 0;
+    HF void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *k) { sink.coop_poseidon_permute(st, k); }
     HF ValBackend(Sink &s, const ValCfg &c, bool zero_cached_) : sink(s), cfg(c), zero_cached(zero_cached_), status(0) {}
 
     HF void fail(uint32_t code) { if (!status) status = code; }
@@ -167,6 +176,17 @@ template <class Sink> struct ValBackend {
         if (cfg.mode == 0) sink.rec(T_CONST4, cfg.proof[w], cfg.proof[w + 1], cfg.proof[w + 2], cfg.proof[w + 3]);
         else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = cfg.proof[w + i]; cell(v); }
     }
+    // ---------------------------------------------------------------- BN254 permutation units
+    HF bool bn_perm_unit(Fr *st, const h2w_poseidon_consts_t *) {
+        if (!cfg.split_bn) return false;
+        fr_t *u = cfg.units + 4 * unit_idx; unit_idx++;
+        for (int i = 0; i < 4; i++) u[i] = st[i];
+        bn_poseidon_native(st, cfg.consts_mont, cfg.P);
+        sink.skip(0, cfg.bn_perm_cells + (zero_cached ? 0 : 1)); zero_cached = true;
+        return true;
+    }
+    HF void bn_perm_begin() { sink.bn_perm_begin(zero_cached); }
+    HF void bn_perm_end() { sink.bn_perm_end(zero_cached); unit_idx++; }
     // ---------------------------------------------------------------- strand hooks
     HF bool merkle_split(int q, int kind) {
         if (!cfg.split) return false;
@@ -174,22 +194,26 @@ template <class Sink> struct ValBackend {
         sink.skip(cfg.st->mk_nrec[s][kind], cfg.st->mk_ncell[s][kind]);
         return true;
     }
-    HF void merkle_begin(int q, int kind) { sink.merkle_begin(q, kind, zero_cached); }
+    HF void merkle_begin(int q, int kind) { sink.merkle_begin(q, kind, zero_cached, unit_idx); }
     HF void merkle_end(int q, int kind) { sink.merkle_end(q, kind, zero_cached); }
-    HF void query_begin(int q) { sink.query_begin(q); }
-    HF void query_end(int q) { sink.query_end(q); }
+    HF void query_begin(int q) { sink.query_begin(q, unit_idx); }
+    HF void query_end(int q) { sink.query_end(q, unit_idx); }
 };
 
 // device sink: records into this proof's record array, direct cells into this proof's advice range
 struct DevSink {
+    static constexpr bool kCoop = false;
+    HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells;
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec++] = r; cell_off += ncells[t]; }
     HF void cell(const fr_t &v) { out[cell_off++] = v; }
     HF void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
-    HF void merkle_begin(int, int, bool) {}
+    HF void merkle_begin(int, int, bool, uint64_t) {}
     HF void merkle_end(int, int, bool) {}
-    HF void query_begin(int) {}
-    HF void query_end(int) {}
+    HF void query_begin(int, uint64_t) {}
+    HF void query_end(int, uint64_t) {}
+    HF void bn_perm_begin(bool) {}
+    HF void bn_perm_end(bool) {}
 };
 
 }  // namespace h2w

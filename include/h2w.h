@@ -151,11 +151,13 @@ int h2w_fri_witness_batch(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_pro
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);
-/* Timing of the last batch call's kernels in ms via HIP events recorded on `stream`
- * (index: 0 = value pass, 1 = expansion, 2 = total).  Blocks until the batch finished. */
-int h2w_plan_last_timing(h2w_plan *, float ms[3]);
-/* Same for the batch `back` calls before the last one (a ring of the last 64 batch calls is kept). */
-int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[3]);
+/* Kernel timing of a batch call, in ms, from HIP events the library records on the call's stream:
+ * ms[0] = prologue strands, ms[1] = query + Merkle strands, ms[2] = expansion kernel, ms[3] = whole batch.
+ * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
+int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[4]);
+int h2w_plan_last_timing(h2w_plan *, float ms[4]);
+/* Advice cells per proof written by the expansion kernel (the rest are written directly by the value kernels). */
+uint64_t h2w_plan_num_record_cells(const h2w_plan *);
 
 #ifdef __cplusplus
 }
