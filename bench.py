@@ -75,6 +75,7 @@ def main():
     import torch.distributed as dist
     h2w = importlib.import_module("halo2-plonky2-verifier_amd")
     api = importlib.import_module("halo2-plonky2-verifier_amd.api")
+    D = importlib.import_module("halo2-plonky2-verifier_amd.distributed")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,9 +113,10 @@ def main():
             pr = O.synth_proof(osh, 0xF1B00000 + i)
             host[i * words:(i + 1) * words] = torch.frombuffer(bytearray(bytes(pr)), dtype=torch.int64)
     all_proofs = host.to(dev)
-    if world > 1:
-        dist.broadcast(all_proofs, src=0)
-    my_proofs = all_proofs[rank * B * words:(rank + 1) * B * words]
+    D.broadcast_proofs(all_proofs, src=0)           # the only collective (RCCL over xGMI): ingest rank -> all ranks
+    lo, hi = D.shard_range(total_proofs, world, rank)
+    assert hi - lo == B
+    my_proofs = all_proofs[lo * words:hi * words]
 
     # S batches in flight: step k runs on stream k % S into its own advice / workspace buffers, so the latency-bound
     # value strands of one batch (serial Fiat-Shamir sponge, Merkle chains) overlap the HBM-bound kernels of another.
@@ -143,10 +145,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
     for i in range(S):
         status = plan.status(wss[i].data_ptr(), B, streams[i].cuda_stream)
         assert status == [0] * B, f"device status {status}"

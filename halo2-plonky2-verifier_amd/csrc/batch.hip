@@ -138,18 +138,75 @@ __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
 }
 
 // PoseidonBN254 permutation units: one lane per permutation (all independent once the chain strands have stored
-// their input states); runs the chip code of hash/poseidon_bn254/permutation.rs:190-203 and writes its 4,032 cells.
+// their input states).  Hand-scheduled restatement of hash/poseidon_bn254/permutation.rs:48-203 that emits the
+// 4,032 cells in the chip's order.  Arithmetic is "hybrid": the state stays CANONICAL (cells are canonical), a
+// constant*variable product is one Montgomery product with the constant pre-multiplied by R, and x^5 takes five
+// (X = x*R; x2 = x*X/R; X2 = X*X/R; x4 = x2*X2/R; x5 = x4*X/R) -> 960 Montgomery products per permutation
+// instead of 2 x 784.  Constants are wave-uniform (scalar loads).
+struct BnEmit {
+    fr_t *out; const h2w_poseidon_consts_t *kc, *km; uint64_t ninv; fr_t r2;
+    __device__ __forceinline__ void put(const fr_t &v) { *out++ = v; }
+    __device__ __forceinline__ void put64(uint64_t v) { fr_t t = fr_from_u64(v); *out++ = t; }
+    __device__ __forceinline__ fr_t exp5(const fr_t &x) {
+        const fr_t X = fr_mont_mul(x, r2, ninv);
+        const fr_t x2 = fr_mont_mul(x, X, ninv), X2 = fr_mont_mul(X, X, ninv);
+        const fr_t x4 = fr_mont_mul(x2, X2, ninv), x5 = fr_mont_mul(x4, X, ninv);
+        put64(0); put(x); put(x); put(x2);
+        put64(0); put(x2); put(x2); put(x4);
+        put64(0); put(x4); put(x); put(x5);
+        return x5;
+    }
+    __device__ __forceinline__ void ark(fr_t *s, int it) {
+        for (int i = 0; i < 4; i++) { const fr_t c = kc->bn_c[it + i]; put(c); put(s[i]); put(c); put64(1); s[i] = fr_add(s[i], c); put(s[i]); }
+    }
+    __device__ __forceinline__ fr_t mul_add(const fr_t &c, const fr_t &cm, const fr_t &x, const fr_t &acc) {   // [acc, c, x, c*x+acc]
+        const fr_t v = fr_add(fr_mont_mul(x, cm, ninv), acc);
+        put(acc); put(c); put(x); put(v);
+        return v;
+    }
+    __device__ __forceinline__ void mix(fr_t *s, const h2w_fr_t (*mc)[4], const h2w_fr_t (*mm)[4], bool &zero_cached) {
+        if (!zero_cached) { put64(0); zero_cached = true; }
+        fr_t ns[4];
+        for (int i = 0; i < 4; i++) { fr_t acc = fr_zero(); for (int j = 0; j < 4; j++) acc = mul_add(mc[j][i], mm[j][i], s[j], acc); ns[i] = acc; }
+        for (int i = 0; i < 4; i++) s[i] = ns[i];
+    }
+    __device__ void permute(fr_t *s, bool zero_cached) {
+        ark(s, 0);
+        for (int half = 0; half < 2; half++) {
+            if (half == 1) {   // partial rounds (:83-110)
+                for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                    s[0] = exp5(s[0]);
+                    const fr_t c = kc->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r];
+                    put(c); put(s[0]); put(c); put64(1); s[0] = fr_add(s[0], c); put(s[0]);
+                    fr_t ns0 = fr_zero();
+                    for (int j = 0; j < 4; j++) { const int ix = (BN_WIDTH * 2 - 1) * r + j; put(kc->bn_s[ix]); ns0 = mul_add(kc->bn_s[ix], km->bn_s[ix], s[j], ns0); }
+                    for (int kk = 1; kk < 4; kk++) { const int ix = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1; put(kc->bn_s[ix]); s[kk] = mul_add(kc->bn_s[ix], km->bn_s[ix], s[0], s[kk]); }
+                    s[0] = ns0;
+                }
+            }
+            // full_rounds(is_first = half == 0) (:112-160)
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(kc->bn_m[i][j]);
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(kc->bn_p[i][j]);
+            for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
+                for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
+                ark(s, half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
+                mix(s, kc->bn_m, km->bn_m, zero_cached);
+            }
+            for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
+            if (half == 0) { ark(s, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(s, kc->bn_p, km->bn_p, zero_cached); }
+            else mix(s, kc->bn_m, km->bn_m, zero_cached);
+        }
+    }
+};
 __global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nu = A.st.total_unit;
     if (idx >= nu * (uint64_t)A.nproofs) return;
     const int p = (int)(idx / nu); const uint64_t u = idx % nu;
-    DevSink sink; sink.recs = nullptr; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = A.unit_cell[u]; sink.ncells = A.ncells;
-    DevB be(sink, make_cfg(A, p), (int64_t)u != A.st.first_zero_unit);
-    PoseidonBN254PermutationChip<DevB> pb(be, A.consts);
+    BnEmit E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.kc = A.consts; E.km = A.consts_mont; E.ninv = A.P.ninv; E.r2 = A.P.r2;
     fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
     for (int i = 0; i < 4; i++) st[i] = in[i];
-    pb.permute(st);
+    E.permute(st, (int64_t)u != A.st.first_zero_unit);
 }
 
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {

@@ -1,0 +1,27 @@
+"""Multi-GPU plumbing for the batched hot path: the path shards by proof with no data-path collective.
+One process per GPU; the ONLY collective is one broadcast of the flat proof block from the ingest rank
+(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_proofs, world, rank):
+    """Contiguous, balanced shard [lo, hi) of `total_proofs` for `rank`."""
+    base, rem = divmod(total_proofs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_proofs(proofs, src=0):
+    """In-place broadcast of the int64 proof block [total_proofs * proof_words] from `src` (no-op when not distributed)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(proofs, src=src)
+    return proofs
+
+
+def max_over_ranks(value, device):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return value
