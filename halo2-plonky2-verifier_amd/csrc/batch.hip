@@ -28,6 +28,9 @@ struct PlanSink {
     std::vector<uint64_t> *meta; const TemplateTable *tt; StrandTable *st;
     uint64_t nrec = 0, cell_off = 0, cur_q_rec = 0, cur_q_cell = 0, mk_rec0 = 0, mk_cell0 = 0; bool mk_zc = false;
     std::vector<uint64_t> *unit_cell = nullptr; uint64_t nunit = 0, cur_q_unit = 0, mk_unit0 = 0; bool pu_zc = false;
+    std::vector<LoadItem> *items = nullptr;
+    void note_load(uint64_t w, int kind) { LoadItem it; it.word = (uint32_t)w; it.kind = (uint32_t)kind; it.rec = nrec; it.cell = cell_off; items->push_back(it); }
+    bool coop_load_proof(const ValCfg &) { return false; }
     void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
     void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
     void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta->push_back(meta_pack((uint32_t)t, cell_off)); nrec++; cell_off += (uint64_t)tt->ncells(t); }
@@ -54,11 +57,13 @@ struct BatchArgs {
     StrandTable st; FrParams P;
     int nproofs;
     fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
+    const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
 };
 
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
     c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = &A.st; c.split = true;
+    c.load_items = A.load_items; c.n_load_items = A.n_load_items; c.load_nrec = A.load_nrec; c.load_ncell = A.load_ncell;
     c.split_bn = false; c.units = A.units + (uint64_t)p * A.unit_stride * 4; c.consts_mont = A.consts_mont; c.bn_perm_cells = A.bn_perm_cells;
     return c;
 }
@@ -75,8 +80,12 @@ __global__ __launch_bounds__(64) void k_prologue(BatchArgs A) {
 
 // one wavefront per proof: wave-uniform gadget code, Goldilocks Poseidon split over 12 lanes (coop.h)
 __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
+    __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
+    __shared__ uint64_t s_k[GLP_CONST_WORDS];
+    for (int i = threadIdx.x; i < GLP_CONST_WORDS; i += 64) s_k[i] = reinterpret_cast<const uint64_t *>(A.consts)[i];
+    __syncthreads();
     const int p = blockIdx.x;
-    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    CoopSink sink; sink.kl = reinterpret_cast<const h2w_poseidon_consts_t *>(s_k); sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x;
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
@@ -85,11 +94,15 @@ __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
 
 // Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot
 __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint64_t s_k[GLP_CONST_WORDS];
+    for (int i = threadIdx.x; i < GLP_CONST_WORDS; i += 64) s_k[i] = reinterpret_cast<const uint64_t *>(A.consts)[i];
+    __syncthreads();
     const int idx = blockIdx.x, nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    CoopSink sink; sink.kl = reinterpret_cast<const h2w_poseidon_consts_t *>(s_k); sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x;
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
@@ -105,6 +118,7 @@ __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
 
 // blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
 __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
+    __builtin_amdgcn_s_setprio(3);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = A.shape.num_queries;
     if (idx >= A.nproofs * nq) return;
@@ -228,10 +242,13 @@ struct h2w_plan {
     TemplateTable tt; DeviceTables dt; StrandTable st; FrParams P;
     Derived d; ProofLayout pl;
     uint64_t nrec = 0, ncells = 0, rec_cells = 0;
+    LoadItem *d_items = nullptr; uint32_t n_items = 0; uint64_t load_nrec = 0, load_ncell = 0;
     uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
-    hipEvent_t evr[EV_RING][4]; hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
+    hipEvent_t evr[EV_RING][4];
+    hipEvent_t t_done; bool t_done_valid = false;   // end of the previous call's emit phase (any stream): emit phases run FIFO
+    hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
 };
 
@@ -252,21 +269,28 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
     if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
     memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1; pl->st.first_zero_unit = -1;
-    std::vector<uint64_t> unit_cell;
+    std::vector<uint64_t> unit_cell; std::vector<LoadItem> items;
     // host inverse table
     std::vector<fr_t> inv(2 * INV_TAB, fr_zero());
     for (int k2 = 1; k2 < INV_TAB; k2++) { inv[k2] = fr_inv(fr_from_u64((uint64_t)k2), pl->P); inv[INV_TAB + k2] = fr_neg(inv[k2]); }
     // shape compile: sequential replay with the counting sink on an all-zero proof
     std::vector<uint64_t> meta; std::vector<uint64_t> zero_proof(pl->pl.total, 0);
     {
-        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st; sink.unit_cell = &unit_cell;
+        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st; sink.unit_cell = &unit_cell; sink.items = &items;
         ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = s.hash_mode; cfg.L = s.lookup_bits; cfg.P = pl->P;
-        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.units = nullptr; cfg.consts_mont = nullptr; cfg.bn_perm_cells = 0;
+        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.units = nullptr; cfg.consts_mont = nullptr; cfg.bn_perm_cells = 0; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
         ValBackend<PlanSink> be(sink, cfg, false);
         Verifier<ValBackend<PlanSink>> V(be, pl->shape, consts);
         ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
         V.run_all(*cb);
         delete cb;
+        pl->n_items = (uint32_t)items.size();
+        if (!items.empty()) {   // records / cells of the load phase: from the first item to the end of the last one
+            // the load phase starts right after the 12 zero-state constants and is contiguous in records and cells
+            const LoadItem &last = items.back();
+            uint64_t last_nrec = last.kind == 3 ? 0 : 1, last_ncell = last.kind == 0 ? (uint64_t)pl->tt.ncells(T_LOADW) : last.kind == 1 ? 1 : last.kind == 2 ? 4 : 1;
+            pl->load_nrec = last.rec + last_nrec - items.front().rec; pl->load_ncell = last.cell + last_ncell - items.front().cell;
+        }
         pl->nrec = sink.nrec; pl->ncells = sink.cell_off; pl->nunit = sink.nunit; pl->st.total_unit = sink.nunit;
         for (uint64_t m : meta) pl->rec_cells += (uint64_t)pl->tt.ncells((int)meta_tmpl(m));
         pl->st.pro_nrec = pl->st.q_rec0[0]; pl->st.pro_ncell = pl->st.q_cell0[0]; pl->st.total_rec = sink.nrec; pl->st.total_cell = sink.cell_off;
@@ -289,6 +313,10 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         if (pl->dt.upload(pl->tt) != 0) return -1;
         H2W_HIP(hipMalloc((void **)&pl->d_meta, meta.size() * sizeof(uint64_t)));
         H2W_HIP(hipMemcpy(pl->d_meta, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (!items.empty()) {
+            H2W_HIP(hipMalloc((void **)&pl->d_items, items.size() * sizeof(LoadItem)));
+            H2W_HIP(hipMemcpy(pl->d_items, items.data(), items.size() * sizeof(LoadItem), hipMemcpyHostToDevice));
+        }
         if (!unit_cell.empty()) {
             H2W_HIP(hipMalloc((void **)&pl->d_unit_cell, unit_cell.size() * sizeof(uint64_t)));
             H2W_HIP(hipMemcpy(pl->d_unit_cell, unit_cell.data(), unit_cell.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -311,6 +339,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         H2W_HIP(hipMalloc((void **)&pl->d_inv, inv.size() * sizeof(fr_t)));
         H2W_HIP(hipMemcpy(pl->d_inv, inv.data(), inv.size() * sizeof(fr_t), hipMemcpyHostToDevice));
         for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 4; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
+        H2W_HIP(hipEventCreateWithFlags(&pl->t_done, hipEventDisableTiming));
         pl->ev_ready = true;
         return 0;
     };
@@ -321,10 +350,12 @@ void h2w_plan_free(h2w_plan *p) {
     if (!p) return;
     if (p->d_meta) (void)hipFree(p->d_meta);
     if (p->d_unit_cell) (void)hipFree(p->d_unit_cell);
+    if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_consts_mont) (void)hipFree(p->d_consts_mont);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
+    if (p->ev_ready) (void)hipEventDestroy(p->t_done);
     if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 4; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
     delete p;
@@ -360,6 +391,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
     A.bn_perm_cells = 4032;
+    A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
     H2W_HIP(hipEventRecord(p->ev[0], stream));
@@ -372,16 +404,21 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         hipLaunchKernelGGL(k_merkle_gl_coop, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
     } else {
         hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+        // emit phase starts here: the HBM-bound kernels of successive calls (issued on different streams) run FIFO,
+        // so the latency-bound value strands of call k+1 overlap the emit phase of call k instead of all calls phase-locking
+        if (p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
         const uint64_t nunits = p->nunit * n_proofs;
         if (nunits) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nunits + 63) / 64)), dim3(64), 0, stream, A);
     }
     H2W_HIP(hipEventRecord(p->ev[1], stream));
+    if (p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
     ExpandArgs E;
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
     p->dt.fill(E); E.rb = p->tt.rb;
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
     launch_expand(E, n_proofs, gx, stream);
     H2W_HIP(hipEventRecord(p->ev[2], stream));
+    H2W_HIP(hipEventRecord(p->t_done, stream)); p->t_done_valid = true;
     p->ev_recorded = true;
     H2W_HIP(hipGetLastError());
     return 0;

@@ -14,11 +14,13 @@ namespace h2w {
 constexpr int GLP_RECS_FULL = 12 + 48 + 1 + 12 * 14;           // constant_layer, sbox_layer, mds_layer
 constexpr int GLP_RECS_PARTIAL_ROUND = 4 + 1 + 1 + 11 + 1 + 11; // sbox, +const, d = m00*s0, d chain, zeros, v row
 constexpr int GLP_RECS_PARTIAL = 12 + 1 + 121 + N_PARTIAL_ROUNDS * GLP_RECS_PARTIAL_ROUND;
+constexpr int GLP_CONST_WORDS = 360 + 12 + 12 + 12 + 22 + 121 + 242 + 242;   // u64 words of the Goldilocks block of h2w_poseidon_consts_t
 constexpr int GLP_RECS = 2 * HALF_N_FULL_ROUNDS * GLP_RECS_FULL + GLP_RECS_PARTIAL;   // 2604
 
 struct CoopSink {
     static constexpr bool kCoop = true;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane;
+    const h2w_poseidon_consts_t *kl;   // Goldilocks-Poseidon round constants + MDS staged in LDS by the kernel (first GLP_CONST_WORDS u64 valid)
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (lane == 0) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec] = r; }
         nrec++; cell_off += ncells[t];
@@ -31,8 +33,22 @@ struct CoopSink {
     __device__ void query_end(int, uint64_t) {}
     __device__ void bn_perm_begin(bool) {}
     __device__ void bn_perm_end(bool) {}
+    __device__ void note_load(uint64_t, int) {}
+    // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
+    __device__ __noinline__ bool coop_load_proof(const ValCfg &cfg) {
+        for (uint32_t i = lane; i < cfg.n_load_items; i += 64) {
+            const LoadItem it = cfg.load_items[i]; const uint64_t *w = cfg.proof + it.word;
+            rec_t r; r.a = w[0]; r.b = 0; r.c = 0; r.d = 0;
+            if (it.kind <= 1) recs[it.rec] = r;
+            else if (it.kind == 2) { r.b = w[1]; r.c = w[2]; r.d = w[3]; recs[it.rec] = r; }
+            else { fr_t v; v.l[0] = w[0]; v.l[1] = w[1]; v.l[2] = w[2]; v.l[3] = w[3]; out[it.cell] = v; }
+        }
+        nrec += cfg.load_nrec; cell_off += cfg.load_ncell;
+        return true;
+    }
 
-    __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *k) {
+    __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
+        const h2w_poseidon_consts_t *k = kl;
         __shared__ uint64_t s_a[SPONGE_WIDTH], s_b[SPONGE_WIDTH];
         rec_t *R = recs + nrec;
         const int l = lane;

@@ -85,7 +85,7 @@ HD gle_t gle_inv(gle_t a) {
 #define H2W_FR_M3 0x30644e72e131a029ULL
 HD uint64_t fr_mod_limb(int i) { return i == 0 ? H2W_FR_M0 : i == 1 ? H2W_FR_M1 : i == 2 ? H2W_FR_M2 : H2W_FR_M3; }
 
-struct FrParams { fr_t r2; uint64_t ninv; };   // 2^512 mod r, -r^{-1} mod 2^64 (derived at init, never typed)
+struct FrParams { fr_t r2; uint64_t ninv; };   // R^2 mod r (R = 2^261), -r^{-1} mod 2^64 (derived at init, never typed)
 
 HD fr_t fr_zero() { fr_t z; z.l[0] = z.l[1] = z.l[2] = z.l[3] = 0; return z; }
 HD fr_t fr_from_u64(uint64_t x) { fr_t z; z.l[0] = x; z.l[1] = z.l[2] = z.l[3] = 0; return z; }
@@ -119,28 +119,78 @@ HD fr_t fr_sub(const fr_t &a, const fr_t &b) {
     return r;
 }
 HD fr_t fr_neg(const fr_t &a) { return fr_sub(fr_zero(), a); }
-// Montgomery product a*b*2^-256 mod r (CIOS, 64-bit limbs -> v_mad_u64_u32 chains on gfx950)
-HNI inline fr_t fr_mont_mul(const fr_t &a, const fr_t &b, uint64_t ninv) {
-    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+// Montgomery product a*b*R^-1 mod r with R = 2^261, on nine 29-bit limbs.
+// Product scanning: a column is at most 18 products < 2^58 plus a carry, so it fits a 64-bit accumulator with NO
+// carry flags at all: every step is one v_mad_u64_u32 into a 64-bit register (full rate on gfx950), columns are
+// closed with a shift.  ~330 VALU ops and wide ILP, against ~770 for 4x64-bit-limb CIOS (carry chains through VCC,
+// register-pair shuffling, hazard nops).  Inputs/outputs are canonical 4x64-bit limbs (cells are stored that way).
+// r in radix 2^29 (derived from H2W_FR_M*, checked by tests): 
+#define H2W_R29_0 0x10000001u
+#define H2W_R29_1 0x1f0fac9fu
+#define H2W_R29_2 0x0e5c2450u
+#define H2W_R29_3 0x07d090f3u
+#define H2W_R29_4 0x1585d283u
+#define H2W_R29_5 0x02db40c0u
+#define H2W_R29_6 0x00a6e141u
+#define H2W_R29_7 0x0e5c2634u
+#define H2W_R29_8 0x0030644eu
+constexpr int FR_MONT_BITS = 261;
+HD fr_t fr_mont_mul(const fr_t &A, const fr_t &B, uint64_t ninv) {
+    const uint32_t MASK = (1u << 29) - 1;
+    const uint32_t N[9] = {H2W_R29_0, H2W_R29_1, H2W_R29_2, H2W_R29_3, H2W_R29_4, H2W_R29_5, H2W_R29_6, H2W_R29_7, H2W_R29_8};
+    const uint32_t ninv29 = (uint32_t)ninv & MASK;            // -r^-1 mod 2^29
+    uint32_t a[9], b[9], m[9], t[9];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 4; i++) {
-        uint64_t bi = b.l[i]; u128 s; uint64_t c;
-        s = (u128)a.l[0] * bi + t0; t0 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)a.l[1] * bi + t1 + c; t1 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)a.l[2] * bi + t2 + c; t2 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)a.l[3] * bi + t3 + c; t3 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)t4 + c; t4 = (uint64_t)s; t5 = (uint64_t)(s >> 64);
-        uint64_t m = t0 * ninv;
-        s = (u128)m * H2W_FR_M0 + t0; c = (uint64_t)(s >> 64);
-        s = (u128)m * H2W_FR_M1 + t1 + c; t0 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)m * H2W_FR_M2 + t2 + c; t1 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)m * H2W_FR_M3 + t3 + c; t2 = (uint64_t)s; c = (uint64_t)(s >> 64);
-        s = (u128)t4 + c; t3 = (uint64_t)s; t4 = t5 + (uint64_t)(s >> 64);
+    for (int j = 0; j < 9; j++) {
+        const int lo = 29 * j, w = lo >> 6, sh = lo & 63;
+        uint64_t xa = A.l[w] >> sh, xb = B.l[w] >> sh;
+        if (sh > 35 && w < 3) { xa |= A.l[w + 1] << (64 - sh); xb |= B.l[w + 1] << (64 - sh); }
+        a[j] = (uint32_t)xa & MASK; b[j] = (uint32_t)xb & MASK;
     }
-    fr_t r; r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3;
-    if (t4 || fr_geq_mod(r)) r = fr_sub_mod_raw(r);
+    uint64_t acc = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 9; k++) {
+        uint64_t e = 0;                                        // second accumulator: halves the dependent-mad chain
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i <= k; i++) { if (i & 1) e += (uint64_t)a[i] * b[k - i]; else acc += (uint64_t)a[i] * b[k - i]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i < k; i++) { if (i & 1) acc += (uint64_t)m[i] * N[k - i]; else e += (uint64_t)m[i] * N[k - i]; }
+        acc += e;
+        m[k] = ((uint32_t)acc * ninv29) & MASK;
+        acc += (uint64_t)m[k] * N[0];
+        acc >>= 29;
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 9; k < 17; k++) {
+        uint64_t e = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = k - 8; i < 9; i++) { if (i & 1) e += (uint64_t)a[i] * b[k - i]; else acc += (uint64_t)a[i] * b[k - i]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = k - 8; i < 9; i++) { if (i & 1) acc += (uint64_t)m[i] * N[k - i]; else e += (uint64_t)m[i] * N[k - i]; }
+        acc += e;
+        t[k - 9] = (uint32_t)acc & MASK; acc >>= 29;
+    }
+    t[8] = (uint32_t)acc;
+    fr_t r;
+    r.l[0] = (uint64_t)t[0] | ((uint64_t)t[1] << 29) | ((uint64_t)t[2] << 58);
+    r.l[1] = ((uint64_t)t[2] >> 6) | ((uint64_t)t[3] << 23) | ((uint64_t)t[4] << 52);
+    r.l[2] = ((uint64_t)t[4] >> 12) | ((uint64_t)t[5] << 17) | ((uint64_t)t[6] << 46);
+    r.l[3] = ((uint64_t)t[6] >> 18) | ((uint64_t)t[7] << 11) | ((uint64_t)t[8] << 40);
+    if (fr_geq_mod(r)) r = fr_sub_mod_raw(r);
     return r;
 }
 // canonical a*b mod r (two Montgomery products)
@@ -154,7 +204,7 @@ inline FrParams fr_params_init() {
     for (int i = 0; i < 6; i++) inv *= 2 - H2W_FR_M0 * inv;
     P.ninv = (uint64_t)0 - inv;
     fr_t x = fr_from_u64(1);
-    for (int i = 0; i < 512; i++) x = fr_add(x, x);
+    for (int i = 0; i < 2 * FR_MONT_BITS; i++) x = fr_add(x, x);   // R^2 mod r, R = 2^261
     P.r2 = x;
     return P;
 }

@@ -27,6 +27,9 @@ HF uint64_t strand_q_unit(const StrandTable &t, int q) { return q == 0 ? t.q_uni
 HF uint64_t strand_q_rec(const StrandTable &t, int q) { return q == 0 ? t.q_rec0[0] : t.q_rec0[1] + (uint64_t)(q - 1) * t.q_nrec[1]; }
 HF uint64_t strand_q_cell(const StrandTable &t, int q) { return q == 0 ? t.q_cell0[0] : t.q_cell0[1] + (uint64_t)(q - 1) * t.q_ncell[1]; }
 
+// one witness-load item of WitnessChip::load_proof_with_pis (built by the shape compiler; consumed by the cooperative loader)
+struct LoadItem { uint32_t word; uint32_t kind; uint64_t rec; uint64_t cell; };   // kind 0: GL load_witness, 1: GL 1-cell, 2: GL hash (4 const cells), 3: BN254 hash (1 cell)
+
 struct ValCfg {
     const uint64_t *proof;           // this proof's flat words
     int mode, L;                     // hash mode, lookup bits
@@ -38,6 +41,7 @@ struct ValCfg {
     fr_t *units;                     // this proof's unit inputs [n_units][4] (split_bn)
     const h2w_poseidon_consts_t *consts_mont;   // constants in Montgomery form (split_bn)
     uint64_t bn_perm_cells;          // cells of one permute call (4032)
+    const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
 };
 
 template <class Sink> struct ValBackend {
@@ -170,9 +174,11 @@ template <class Sink> struct ValBackend {
         else { for (int i = 0; i < 4; i++) { h.f.l[i] = cfg.proof[w + i]; h.e[i] = 0; } }
         return h;
     }
-    HF void load_proof_gl(uint64_t w) { gl_witness(cfg.proof[w]); }
-    HF void load_proof_gl_nocheck(uint64_t w) { sink.rec(T_CONST1, cfg.proof[w], 0, 0, 0); }
+    HF bool coop_load_proof() { return sink.coop_load_proof(cfg); }
+    HF void load_proof_gl(uint64_t w) { sink.note_load(w, 0); gl_witness(cfg.proof[w]); }
+    HF void load_proof_gl_nocheck(uint64_t w) { sink.note_load(w, 1); sink.rec(T_CONST1, cfg.proof[w], 0, 0, 0); }
     HF void load_proof_hash(uint64_t w) {
+        sink.note_load(w, cfg.mode == 0 ? 2 : 3);
         if (cfg.mode == 0) sink.rec(T_CONST4, cfg.proof[w], cfg.proof[w + 1], cfg.proof[w + 2], cfg.proof[w + 3]);
         else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = cfg.proof[w + i]; cell(v); }
     }
@@ -214,6 +220,8 @@ struct DevSink {
     HF void query_end(int, uint64_t) {}
     HF void bn_perm_begin(bool) {}
     HF void bn_perm_end(bool) {}
+    HF void note_load(uint64_t, int) {}
+    HF bool coop_load_proof(const ValCfg &) { return false; }
 };
 
 }  // namespace h2w

@@ -57,6 +57,7 @@ template <class B> struct Verifier {
     // ---- WitnessChip::load_proof_with_pis (witness/mod.rs:267-294), in flat-layout order
     HF void load_gl(uint64_t w) { if (s.witness_load_range_check) be.load_proof_gl(w); else be.load_proof_gl_nocheck(w); }   // :48-51
     HNI void load_proof_with_pis() {
+        if (be.coop_load_proof()) return;      // device prologue wavefront: items striped over the 64 lanes (coop.h)
         uint64_t w = 0;
         for (int i = 0; i < 2 * d.cap_size; i++, w += 4) be.load_proof_hash(w);                 // trace_cap, quotient_polys_cap (:245-246)
         uint64_t n_open = 2ull * (2 * s.n_cols + 2 * s.n_perm_z + s.n_quotient);

@@ -10,10 +10,9 @@ constexpr int ITER = 4096;
 
 __global__ void k_mad64(uint64_t *o, uint32_t a, uint32_t b) {   // 8 independent v_mad_u64_u32 chains
     uint64_t x[8]; for (int i = 0; i < 8; i++) x[i] = threadIdx.x + i;
-    uint32_t aa = a + threadIdx.x, bb = b;
     for (int it = 0; it < ITER; it++) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = (uint64_t)aa * (uint32_t)(bb + i) + x[i];
+        for (int i = 0; i < 8; i++) x[i] = (uint64_t)(uint32_t)x[i] * (uint32_t)(x[i] >> 32) + x[(i + 1) & 7];   // operands change every iteration
     }
     uint64_t s = 0; for (int i = 0; i < 8; i++) s ^= x[i]; o[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
