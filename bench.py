@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# several batches are in flight on separate HIP streams; ROCm maps streams onto 4 hardware queues by default, which would
+# serialise them pairwise.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 CONFIGS = {
     # name: (degree_bits, num_queries, rate_bits, description)

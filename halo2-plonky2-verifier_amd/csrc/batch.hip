@@ -12,6 +12,7 @@
 #include <vector>
 #include <string>
 #include <cstring>
+#include <cstdlib>
 #include "common.h"
 #include "valbackend.h"
 #include "coop.h"
@@ -157,10 +158,36 @@ __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
 // constant*variable product is one Montgomery product with the constant pre-multiplied by R, and x^5 takes five
 // (X = x*R; x2 = x*X/R; X2 = X*X/R; x4 = x2*X2/R; x5 = x4*X/R) -> 960 Montgomery products per permutation
 // instead of 2 x 784.  Constants are wave-uniform (scalar loads).
-struct BnEmit {
+// Stores: STAGED = true stages BN_CH cells per lane in LDS ([cell][lane], rows padded by 32 B) and lets the wavefront
+// flush them as whole 128-B lines (4 permutations x 512 contiguous bytes per store instruction) instead of 64 scattered
+// 32-byte stores; all lanes of the wave are in lockstep (same cell count), which the one odd unit with the cached
+// load_zero cell would break, so that unit runs in its own launch with STAGED = false.
+constexpr int BN_CH = 16;
+constexpr int BN_ROW = 64 * 32 + 32;   // bytes per staged cell row
+template <bool STAGED> struct BnEmit {
     fr_t *out; const h2w_poseidon_consts_t *kc, *km; uint64_t ninv; fr_t r2;
-    __device__ __forceinline__ void put(const fr_t &v) { *out++ = v; }
-    __device__ __forceinline__ void put64(uint64_t v) { fr_t t = fr_from_u64(v); *out++ = t; }
+    char *lds; int lane, cnt;
+    __device__ __forceinline__ void flush() {
+        typedef unsigned long long ull; struct __attribute__((aligned(16))) q16 { ull x, y; };
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
+        const unsigned long long mydst = (unsigned long long)out;
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int P = it * 4 + (lane >> 4), k = (lane & 15) >> 1, h = lane & 1;
+            const unsigned long long d = __shfl(mydst, P, 64);
+            // lane handles 16 B: cell k and cell k+8 of permutation P (two stores: 2 x 256 B per permutation each)
+            const q16 v0 = *reinterpret_cast<const q16 *>(lds + k * BN_ROW + P * 32 + h * 16);
+            const q16 v1 = *reinterpret_cast<const q16 *>(lds + (k + 8) * BN_ROW + P * 32 + h * 16);
+            *reinterpret_cast<q16 *>(d + (unsigned long long)(k * 32 + h * 16)) = v0;
+            *reinterpret_cast<q16 *>(d + (unsigned long long)((k + 8) * 32 + h * 16)) = v1;
+        }
+        out += BN_CH; cnt = 0;
+    }
+    __device__ __forceinline__ void put(const fr_t &v) {
+        if (STAGED) { *reinterpret_cast<fr_t *>(lds + cnt * BN_ROW + lane * 32) = v; if (++cnt == BN_CH) flush(); }
+        else *out++ = v;
+    }
+    __device__ __forceinline__ void put64(uint64_t v) { fr_t t = fr_from_u64(v); put(t); }
     __device__ __forceinline__ fr_t exp5(const fr_t &x) {
         const fr_t X = fr_mont_mul(x, r2, ninv);
         const fr_t x2 = fr_mont_mul(x, X, ninv), X2 = fr_mont_mul(X, X, ninv);
@@ -212,15 +239,31 @@ struct BnEmit {
         }
     }
 };
+// grid: every (proof, unit) except the one unit per proof that carries the Context's first load_zero cell
 __global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t nu = A.st.total_unit;
-    if (idx >= nu * (uint64_t)A.nproofs) return;
-    const int p = (int)(idx / nu); const uint64_t u = idx % nu;
-    BnEmit E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.kc = A.consts; E.km = A.consts_mont; E.ninv = A.P.ninv; E.r2 = A.P.r2;
+    __shared__ __attribute__((aligned(16))) char s_stage[BN_CH * BN_ROW];
+    const uint64_t nu = A.st.total_unit, nreg = A.st.first_zero_unit >= 0 ? nu - 1 : nu;
+    const uint64_t total = nreg * (uint64_t)A.nproofs;
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) idx = total - 1;                 // tail lanes redo the last unit (identical bytes) to keep the wave in lockstep
+    const int p = (int)(idx / nreg); uint64_t u = idx % nreg;
+    if (A.st.first_zero_unit >= 0 && u >= (uint64_t)A.st.first_zero_unit) u++;
+    BnEmit<true> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.kc = A.consts; E.km = A.consts_mont; E.ninv = A.P.ninv; E.r2 = A.P.r2;
+    E.lds = s_stage; E.lane = threadIdx.x; E.cnt = 0;
     fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
     for (int i = 0; i < 4; i++) st[i] = in[i];
-    E.permute(st, (int64_t)u != A.st.first_zero_unit);
+    E.permute(st, true);
+}
+// the odd unit (4,033 cells): one lane per proof, direct stores
+__global__ __launch_bounds__(64) void k_bn_unit_zero(BatchArgs A) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.nproofs || A.st.first_zero_unit < 0) return;
+    const uint64_t u = (uint64_t)A.st.first_zero_unit;
+    BnEmit<false> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.kc = A.consts; E.km = A.consts_mont; E.ninv = A.P.ninv; E.r2 = A.P.r2;
+    E.lds = nullptr; E.lane = 0; E.cnt = 0;
+    fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
+    for (int i = 0; i < 4; i++) st[i] = in[i];
+    E.permute(st, false);
 }
 
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
@@ -247,6 +290,7 @@ struct h2w_plan {
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
     hipEvent_t evr[EV_RING][4];
+    bool fifo_emit = false;   // H2W_FIFO_EMIT=1: serialise the emit phases of successive calls (diagnostic)
     hipEvent_t t_done; bool t_done_valid = false;   // end of the previous call's emit phase (any stream): emit phases run FIFO
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
@@ -266,6 +310,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     }
     h2w_plan *pl = new h2w_plan(s.lookup_bits);
     pl->shape = s; pl->device = device_id; pl->P = fr_params_init();
+    { const char *e = getenv("H2W_FIFO_EMIT"); pl->fifo_emit = e && e[0] == '1'; }
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
     if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
     memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1; pl->st.first_zero_unit = -1;
@@ -406,12 +451,13 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
         // emit phase starts here: the HBM-bound kernels of successive calls (issued on different streams) run FIFO,
         // so the latency-bound value strands of call k+1 overlap the emit phase of call k instead of all calls phase-locking
-        if (p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
-        const uint64_t nunits = p->nunit * n_proofs;
-        if (nunits) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nunits + 63) / 64)), dim3(64), 0, stream, A);
+        if (p->fifo_emit && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
+        const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
+        if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, stream, A);
+        if (p->st.first_zero_unit >= 0) hipLaunchKernelGGL(k_bn_unit_zero, dim3((unsigned)((n_proofs + 63) / 64)), dim3(64), 0, stream, A);
     }
     H2W_HIP(hipEventRecord(p->ev[1], stream));
-    if (p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
+    if (p->fifo_emit && p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
     ExpandArgs E;
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
     p->dt.fill(E); E.rb = p->tt.rb;
