@@ -21,7 +21,8 @@ namespace h2w {
 
 typedef ValBackend<DevSink> DevB;
 typedef ChallengeBlock<DevB> DevCB;
-typedef ValBackend<CoopSink> CoopB;   // same wire types as DevB: ChallengeBlock layouts coincide
+typedef ValBackend<CoopSink> CoopB;
+typedef ValBackend<QuadSink> QuadB;   // same wire types as DevB: ChallengeBlock layouts coincide
 
 struct PlanSink {
     static constexpr bool kCoop = false;
@@ -32,6 +33,7 @@ struct PlanSink {
     std::vector<LoadItem> *items = nullptr;
     void note_load(uint64_t w, int kind) { LoadItem it; it.word = (uint32_t)w; it.kind = (uint32_t)kind; it.rec = nrec; it.cell = cell_off; items->push_back(it); }
     bool coop_load_proof(const ValCfg &) { return false; }
+    void bn_native(fr_t *, const h2w_poseidon_consts_t *, const FrParams &) {}
     void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
     void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
     void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta->push_back(meta_pack((uint32_t)t, cell_off)); nrec++; cell_off += (uint64_t)tt->ncells(t); }
@@ -56,7 +58,7 @@ struct BatchArgs {
     DevCB *cbs; uint32_t *status;
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
     StrandTable st; FrParams P;
-    int nproofs;
+    int nproofs, role_base;
     fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
 };
@@ -117,13 +119,53 @@ __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
     if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
+// PoseidonBN254 Merkle chain strands (hash_mode 1): four lanes per (proof, query, kind); blockIdx.y = kind slot
+__device__ void glue_lane(const BatchArgs &A, int idx) {   // FriChip::verify_query_round minus its Merkle proofs: one lane per (proof, query)
+    const int nq = A.shape.num_queries;
+    const int p = idx / nq, q = idx % nq;
+    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells;
+    sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
+    DevB be(sink, make_cfg(A, p), true);
+    Verifier<DevB> V(be, A.shape, A.consts);
+    V.query_round(q, A.cbs[p]);
+    if (be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+__global__ __launch_bounds__(64) void k_merkle_bn_quad(BatchArgs A) {
+    __builtin_amdgcn_s_setprio(3);
+    const int nq = A.shape.num_queries, total = A.nproofs * nq;
+    if ((int)blockIdx.y == A.role_base) {               // last y slot: the query glue strands, one lane each
+        const int gi = blockIdx.x * 64 + threadIdx.x;
+        if (gi < total) glue_lane(A, gi);
+        return;
+    }
+    int idx = (blockIdx.x * 64 + threadIdx.x) >> 2;
+    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes): keeps shuffles in-quad valid
+    const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    QuadSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3;
+    sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
+    ValCfg mc = make_cfg(A, p); mc.split_bn = true;
+    QuadB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
+    be.unit_idx = strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind];
+    Verifier<QuadB> V(be, A.shape, A.consts);
+    const uint64_t x = A.cbs[p].fri_query_indices[q];
+    const int lde = V.d.lde_bits; int lo = 0;
+    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
+    uint64_t bits[64]; const int nb = lde - lo;
+    for (int i = 0; i < nb; i++) bits[i] = (x >> (lo + i)) & 1;
+    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
+    V.merkle_strand(q, kind, bits, nb, cap_index);
+    if ((threadIdx.x & 3) == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+
 // blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
 __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
     __builtin_amdgcn_s_setprio(3);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = A.shape.num_queries;
     if (idx >= A.nproofs * nq) return;
-    const int p = idx / nq, q = idx % nq, role = blockIdx.y, sq = q == 0 ? 0 : 1;
+    const int p = idx / nq, q = idx % nq, role = A.role_base + blockIdx.y, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;   // initial oracles
     DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells;
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
@@ -244,7 +286,19 @@ __global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
     __shared__ __attribute__((aligned(16))) char s_stage[BN_CH * BN_ROW];
     const uint64_t nu = A.st.total_unit, nreg = A.st.first_zero_unit >= 0 ? nu - 1 : nu;
     const uint64_t total = nreg * (uint64_t)A.nproofs;
-    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t zblocks = A.st.first_zero_unit >= 0 ? ((uint64_t)A.nproofs + 63) / 64 : 0;
+    if (blockIdx.x < zblocks) {   // leading blocks (dispatched first: they are the slowest): the odd unit (4,033 cells) of each proof, direct stores
+        const uint64_t zp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (zp < (uint64_t)A.nproofs && A.st.first_zero_unit >= 0) {
+            const uint64_t uz = (uint64_t)A.st.first_zero_unit;
+            BnEmit<false> Z; Z.out = A.out + zp * A.cell_stride + A.unit_cell[uz]; Z.kc = A.consts; Z.km = A.consts_mont; Z.ninv = A.P.ninv; Z.r2 = A.P.r2; Z.lds = nullptr; Z.lane = 0; Z.cnt = 0;
+            fr_t zs[4]; const fr_t *zin = A.units + (zp * A.unit_stride + uz) * 4;
+            for (int i = 0; i < 4; i++) zs[i] = zin[i];
+            Z.permute(zs, false);
+        }
+        return;
+    }
+    uint64_t idx = ((uint64_t)blockIdx.x - zblocks) * blockDim.x + threadIdx.x;
     if (idx >= total) idx = total - 1;                 // tail lanes redo the last unit (identical bytes) to keep the wave in lockstep
     const int p = (int)(idx / nreg); uint64_t u = idx % nreg;
     if (A.st.first_zero_unit >= 0 && u >= (uint64_t)A.st.first_zero_unit) u++;
@@ -435,7 +489,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = p->ncells;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
-    A.bn_perm_cells = 4032;
+    A.bn_perm_cells = 4032; A.role_base = 0;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
@@ -448,13 +502,15 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
         hipLaunchKernelGGL(k_merkle_gl_coop, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
     } else {
-        hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+        // BN254 Merkle chain strands (4 lanes each), then the query glue (1 lane each)
+        A.role_base = p->d.n_oracles + p->d.n_steps;   // y slot of the glue strands
+        hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + 63) / 64, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(64), 0, stream, A);
         // emit phase starts here: the HBM-bound kernels of successive calls (issued on different streams) run FIFO,
         // so the latency-bound value strands of call k+1 overlap the emit phase of call k instead of all calls phase-locking
         if (p->fifo_emit && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
         const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
-        if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, stream, A);
-        if (p->st.first_zero_unit >= 0) hipLaunchKernelGGL(k_bn_unit_zero, dim3((unsigned)((n_proofs + 63) / 64)), dim3(64), 0, stream, A);
+        const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
+        if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64 + zblocks)), dim3(64), 0, stream, A);
     }
     H2W_HIP(hipEventRecord(p->ev[1], stream));
     if (p->fifo_emit && p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));

@@ -34,6 +34,7 @@ struct CoopSink {
     __device__ void bn_perm_begin(bool) {}
     __device__ void bn_perm_end(bool) {}
     __device__ void note_load(uint64_t, int) {}
+    __device__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
     // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
     __device__ __noinline__ bool coop_load_proof(const ValCfg &cfg) {
         for (uint32_t i = lane; i < cfg.n_load_items; i += 64) {
@@ -138,6 +139,69 @@ struct CoopSink {
         const uint64_t full_cells = 12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA);
         const uint64_t part_cells = 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
         nrec += GLP_RECS; cell_off += 2 * HALF_N_FULL_ROUNDS * full_cells + part_cells;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// QuadSink: four adjacent lanes execute one BN254 Merkle chain strand quad-uniformly (lane 0 of the quad writes the
+// strand's direct cells) and split the width-4 PoseidonBN254 state between them for the value-domain permutation:
+// full rounds 4-way parallel (x^5, then each lane one output row of the mix), partial rounds: lane 0 does the S-box,
+// all four lanes one product of the sparse row, lanes 1-3 their column update (5 instead of 14 dependent products).
+struct QuadSink {
+    static constexpr bool kCoop = false;
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4;
+    __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+        if (l4 == 0) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec] = r; }
+        nrec++; cell_off += ncells[t];
+    }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) out[cell_off] = v; cell_off++; }
+    __device__ __forceinline__ void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
+    __device__ void merkle_begin(int, int, bool, uint64_t) {}
+    __device__ void merkle_end(int, int, bool) {}
+    __device__ void query_begin(int, uint64_t) {}
+    __device__ void query_end(int, uint64_t) {}
+    __device__ void bn_perm_begin(bool) {}
+    __device__ void bn_perm_end(bool) {}
+    __device__ void note_load(uint64_t, int) {}
+    __device__ bool coop_load_proof(const ValCfg &) { return false; }
+    __device__ void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
+    static __device__ __forceinline__ fr_t shfl4(const fr_t &v, int src) {     // value of lane `src` of this quad
+        fr_t r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.l[i] = __shfl(v.l[i], src, 4);
+        return r;
+    }
+    static __device__ __forceinline__ fr_t shfl4_xor(const fr_t &v, int m) {
+        fr_t r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.l[i] = __shfl_xor(v.l[i], m, 4);
+        return r;
+    }
+    __device__ __noinline__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) {
+        const int l = l4; const uint64_t ninv = P.ninv;
+        fr_t mine = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
+        fr_t s = fr_mont_mul(mine, P.r2, ninv);
+        auto exp5 = [&](const fr_t &x) { fr_t x2 = fr_mont_mul(x, x, ninv), x4 = fr_mont_mul(x2, x2, ninv); return fr_mont_mul(x4, x, ninv); };
+        auto mix = [&](const h2w_fr_t (*m)[4]) {
+            fr_t acc = fr_zero();
+            for (int j = 0; j < 4; j++) { const fr_t sj = shfl4(s, j); acc = fr_add(acc, fr_mont_mul(m[j][l], sj, ninv)); }
+            s = acc;
+        };
+        s = fr_add(s, km->bn_c[l]);
+        for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { s = exp5(s); s = fr_add(s, km->bn_c[(r + 1) * BN_WIDTH + l]); mix(km->bn_m); }
+        s = exp5(s); s = fr_add(s, km->bn_c[(BN_FULL_ROUNDS / 2) * BN_WIDTH + l]); mix(km->bn_p);
+        for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+            if (l == 0) s = fr_add(exp5(s), km->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]);
+            const fr_t s0 = shfl4(s, 0);
+            fr_t p = fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + l], s, ninv);            // S[j] * s_j
+            if (l > 0) s = fr_add(s, fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + BN_WIDTH + l - 1], s0, ninv));
+            p = fr_add(p, shfl4_xor(p, 1)); p = fr_add(p, shfl4_xor(p, 2));                     // sum over the quad
+            if (l == 0) s = p;
+        }
+        for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { s = exp5(s); s = fr_add(s, km->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH + l]); mix(km->bn_m); }
+        s = exp5(s); mix(km->bn_m);
+        const fr_t o = fr_mont_mul(s, fr_from_u64(1), ninv);
+        for (int j = 0; j < 4; j++) st[j] = shfl4(o, j);
     }
 };
 

@@ -9,15 +9,15 @@
 #include <hip/hip_runtime.h>
 #include "records.h"
 #include "common.h"
+#include <cstdlib>
 
 namespace h2w {
 
-constexpr int TILE_RECS = 32;
 constexpr int EXPAND_THREADS = 256;
 typedef unsigned long long ull;
 struct __attribute__((aligned(16))) u128s { ull lo, hi; };
 
-__global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel(ExpandArgs A) {
+template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_t(ExpandArgs A) {
     __shared__ uint32_t s_slots[MAX_SLOTS];
     __shared__ u128s s_consts[MAX_CONSTS * 2];
     __shared__ tmpl_info_t s_info[T_MAX];
@@ -86,13 +86,16 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel(ExpandArgs A) {
         const uint32_t total = s_pre[nr];
         for (uint32_t j = tid; j < total; j += EXPAND_THREADS) {
             int lo = 0, hi = nr;     // find i: pre[i] <= j < pre[i+1]
+            if (ABLATE == 0) {
 #pragma unroll
-            for (int it = 0; it < 5; it++) { int mid = (lo + hi) >> 1; if (s_pre[mid] <= j) lo = mid; else hi = mid; }
+                for (int it = 0; it < NSTEP; it++) { int mid = (lo + hi) >> 1; if (s_pre[mid] <= j) lo = mid; else hi = mid; }
+            } else lo = (int)(j / 66u) < nr ? (int)(j / 66u) : nr - 1;        // timing-only ablation (wrong cells)
             const int i = lo;
-            const uint32_t s = j - s_pre[i];
+            const uint32_t s = ABLATE == 0 ? j - s_pre[i] : j % 60u;
             u128s vlo, vhi; vhi.lo = 0; vhi.hi = 0;
             const ull lit = s_lit[i];
-            if (lit != ~0ull) {
+            if (ABLATE == 2) { vlo.lo = j; vlo.hi = lit; }
+            else if (lit != ~0ull) {
                 const u128s *src = (const u128s *)(A.pool + lit + s);
                 vlo = src[0]; vhi = src[1];
             } else {
@@ -108,19 +111,214 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel(ExpandArgs A) {
                     vlo.lo = (ull)v; vlo.hi = (ull)(v >> 64);
                 }
             }
-            u128s *dst = (u128s *)(out + s_coff[i] + s);
+            u128s *dst = ABLATE == 0 ? (u128s *)(out + s_coff[i] + s) : (u128s *)(out + s_coff[0] + j);
             dst[0] = vlo; dst[1] = vhi;
         }
         __syncthreads();
     }
 }
 
+
+// ---- variant 1: wave-level tiles.  Each 64-lane wavefront owns a tile of 64 records: all 64 lanes derive bases (one
+// record each), then the wave streams the tile's cells.  No workgroup barrier in the loop (a wave is in lockstep), so
+// the 4 waves of a workgroup overlap their record phases and store phases freely.
+constexpr int WTILE = 64;
+__global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_w(ExpandArgs A) {
+    __shared__ uint32_t s_slots[MAX_SLOTS];
+    __shared__ u128s s_consts[MAX_CONSTS * 2];
+    __shared__ tmpl_info_t s_info[T_MAX];
+    __shared__ u128s s_bases[4][WTILE][B_COUNT];
+    __shared__ uint32_t s_pre[4][WTILE + 1];
+    __shared__ uint32_t s_sbase[4][WTILE];
+    __shared__ ull s_coff[4][WTILE];
+    __shared__ ull s_lit[4][WTILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t i = tid; i < A.nslots; i += EXPAND_THREADS) s_slots[i] = A.slots[i];
+    for (uint32_t i = tid; i < A.nconsts * 2; i += EXPAND_THREADS) s_consts[i] = ((const u128s *)A.consts)[i];
+    for (uint32_t i = tid; i < A.ntmpl; i += EXPAND_THREADS) s_info[i] = A.info[i];
+    __syncthreads();
+
+    const uint64_t proof = blockIdx.y;
+    const rec_t *recs = A.recs + proof * A.rec_stride;
+    fr_t *out = A.out + proof * A.cell_stride;
+    const uint64_t ntiles = (A.nrec + WTILE - 1) / WTILE;
+    const u128 two_rb = (u128)1 << A.rb;
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
+        const uint64_t r0 = tile * WTILE;
+        const int nr = (int)((A.nrec - r0) < WTILE ? (A.nrec - r0) : WTILE);
+        uint32_t n = 0;
+        if (lane < nr) {
+            const uint64_t m = A.meta[r0 + lane];
+            const rec_t rc = recs[r0 + lane];
+            const uint32_t t = meta_tmpl(m);
+            const tmpl_info_t ti = s_info[t];
+            n = ti.ncells;
+            s_sbase[wv][lane] = ti.slot_base;
+            s_coff[wv][lane] = meta_off(m);
+            s_lit[wv][lane] = ~0ull;
+            if (t == T_LITERAL) { n = (uint32_t)rc.b; s_lit[wv][lane] = rc.a; }
+            u128 V, X0, X1;
+            if (ti.mode == M_WIDEV) V = ((u128)rc.b << 64) | rc.a; else V = (u128)rc.a * rc.b + rc.c;
+            if (ti.mode == M_LOADW) { X0 = rc.a; X1 = rc.b; }
+            else {
+                const uint64_t r = gl_reduce128(V);
+                const u128 Dv = V - r;
+                const uint64_t dl = (uint64_t)Dv;
+                const uint64_t qlo = dl + (dl << 32);
+                const uint64_t qhi = ((u128)qlo * GL_P != Dv) ? 1 : 0;
+                X0 = gl_reduce128(((u128)qhi << 64) | qlo); X1 = r;
+            }
+            u128 b[B_COUNT];
+            b[B_A] = rc.a; b[B_B] = rc.b; b[B_C] = rc.c; b[B_D] = rc.d; b[B_V] = V;
+            b[B_X0] = X0; b[B_X0P] = X0 + two_rb - GL_P; b[B_X0PP] = X0 + two_rb;
+            b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb;
+#pragma unroll
+            for (int k = 0; k < B_COUNT; k++) { s_bases[wv][lane][k].lo = (ull)b[k]; s_bases[wv][lane][k].hi = (ull)(b[k] >> 64); }
+        }
+        uint32_t x = n;
+#pragma unroll
+        for (int d = 1; d < WTILE; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        s_pre[wv][lane + 1] = x;
+        if (lane == 0) s_pre[wv][0] = 0;
+        const uint32_t total = __shfl(x, 63, 64);
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // this wave's LDS writes are visible to its own later reads (in-order LDS)
+        for (uint32_t j = lane; j < total; j += 64) {
+            int lo = 0, hi = nr;
+#pragma unroll
+            for (int it = 0; it < 6; it++) { int mid = (lo + hi) >> 1; if (s_pre[wv][mid] <= j) lo = mid; else hi = mid; }
+            const int i = lo;
+            const uint32_t s = j - s_pre[wv][i];
+            u128s vlo, vhi; vhi.lo = 0; vhi.hi = 0;
+            const ull lit = s_lit[wv][i];
+            if (lit != ~0ull) { const u128s *src = (const u128s *)(A.pool + lit + s); vlo = src[0]; vhi = src[1]; }
+            else {
+                const uint32_t d = s_slots[s_sbase[wv][i] + s];
+                if (d & 0x80000000u) { vlo = s_consts[(d & 0xffffu) * 2]; vhi = s_consts[(d & 0xffffu) * 2 + 1]; }
+                else {
+                    const u128s bs = s_bases[wv][i][d & 15u];
+                    u128 v = ((u128)bs.hi << 64) | bs.lo;
+                    const uint32_t sh = (d >> 4) & 127u, w = (d >> 11) & 255u, ls = (d >> 19) & 127u;
+                    v >>= sh;
+                    if (w < 128) v &= (((u128)1 << w) - 1);
+                    v <<= ls;
+                    vlo.lo = (ull)v; vlo.hi = (ull)(v >> 64);
+                }
+            }
+            u128s *dst = (u128s *)(out + s_coff[wv][i] + s);
+            dst[0] = vlo; dst[1] = vhi;
+        }
+    }
+}
+
+
+// ---- variant 2: wave-level tiles, one record per wave iteration (no cell->record search).
+// Lane = record derives bases; then for each record r of the tile the 64 lanes write its cells 0..63 (record fields
+// are wave-uniform), and the 1-2 leftover cells of the 65/66-cell Goldilocks blocks are written lane-per-record.
+__device__ __forceinline__ void eval_cell(uint32_t d, const u128s *bases, const u128s *consts, u128s &vlo, u128s &vhi) {
+    vhi.lo = 0; vhi.hi = 0;
+    if (d & 0x80000000u) { vlo = consts[(d & 0xffffu) * 2]; vhi = consts[(d & 0xffffu) * 2 + 1]; }
+    else {
+        const u128s bs = bases[d & 15u];
+        u128 v = ((u128)bs.hi << 64) | bs.lo;
+        const uint32_t sh = (d >> 4) & 127u, w = (d >> 11) & 255u, ls = (d >> 19) & 127u;
+        v >>= sh;
+        if (w < 128) v &= (((u128)1 << w) - 1);
+        v <<= ls;
+        vlo.lo = (ull)v; vlo.hi = (ull)(v >> 64);
+    }
+}
+__global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_r(ExpandArgs A) {
+    __shared__ uint32_t s_slots[MAX_SLOTS];
+    __shared__ u128s s_consts[MAX_CONSTS * 2];
+    __shared__ tmpl_info_t s_info[T_MAX];
+    __shared__ u128s s_bases[4][WTILE][B_COUNT];
+    __shared__ uint32_t s_n[4][WTILE];
+    __shared__ uint32_t s_sbase[4][WTILE];
+    __shared__ ull s_coff[4][WTILE];
+    __shared__ ull s_lit[4][WTILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t i = tid; i < A.nslots; i += EXPAND_THREADS) s_slots[i] = A.slots[i];
+    for (uint32_t i = tid; i < A.nconsts * 2; i += EXPAND_THREADS) s_consts[i] = ((const u128s *)A.consts)[i];
+    for (uint32_t i = tid; i < A.ntmpl; i += EXPAND_THREADS) s_info[i] = A.info[i];
+    __syncthreads();
+
+    const uint64_t proof = blockIdx.y;
+    const rec_t *recs = A.recs + proof * A.rec_stride;
+    fr_t *out = A.out + proof * A.cell_stride;
+    const uint64_t ntiles = (A.nrec + WTILE - 1) / WTILE;
+    const u128 two_rb = (u128)1 << A.rb;
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
+        const uint64_t r0 = tile * WTILE;
+        const int nr = (int)((A.nrec - r0) < WTILE ? (A.nrec - r0) : WTILE);
+        uint32_t n = 0, my_sbase = 0; ull my_coff = 0, my_lit = ~0ull;
+        if (lane < nr) {
+            const uint64_t m = A.meta[r0 + lane];
+            const rec_t rc = recs[r0 + lane];
+            const uint32_t t = meta_tmpl(m);
+            const tmpl_info_t ti = s_info[t];
+            n = ti.ncells; my_sbase = ti.slot_base; my_coff = meta_off(m);
+            if (t == T_LITERAL) { n = (uint32_t)rc.b; my_lit = rc.a; }
+            u128 V, X0, X1;
+            if (ti.mode == M_WIDEV) V = ((u128)rc.b << 64) | rc.a; else V = (u128)rc.a * rc.b + rc.c;
+            if (ti.mode == M_LOADW) { X0 = rc.a; X1 = rc.b; }
+            else {
+                const uint64_t r = gl_reduce128(V);
+                const u128 Dv = V - r;
+                const uint64_t dl = (uint64_t)Dv;
+                const uint64_t qlo = dl + (dl << 32);
+                const uint64_t qhi = ((u128)qlo * GL_P != Dv) ? 1 : 0;
+                X0 = gl_reduce128(((u128)qhi << 64) | qlo); X1 = r;
+            }
+            u128 b[B_COUNT];
+            b[B_A] = rc.a; b[B_B] = rc.b; b[B_C] = rc.c; b[B_D] = rc.d; b[B_V] = V;
+            b[B_X0] = X0; b[B_X0P] = X0 + two_rb - GL_P; b[B_X0PP] = X0 + two_rb;
+            b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb;
+#pragma unroll
+            for (int k = 0; k < B_COUNT; k++) { s_bases[wv][lane][k].lo = (ull)b[k]; s_bases[wv][lane][k].hi = (ull)(b[k] >> 64); }
+        }
+        s_n[wv][lane] = n; s_sbase[wv][lane] = my_sbase; s_coff[wv][lane] = my_coff; s_lit[wv][lane] = my_lit;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int r = 0; r < nr; r++) {
+            const uint32_t nn = s_n[wv][r]; const ull coff = s_coff[wv][r], lit = s_lit[wv][r];
+            const bool big = nn > 128 || lit != ~0ull;            // literal runs / long records: full strided loop here
+            const uint32_t lim = big ? nn : (nn < 64 ? nn : 64);
+            for (uint32_t sidx = lane; sidx < lim; sidx += 64) {
+                u128s vlo, vhi;
+                if (lit != ~0ull) { const u128s *src = (const u128s *)(A.pool + lit + sidx); vlo = src[0]; vhi = src[1]; }
+                else eval_cell(s_slots[s_sbase[wv][r] + sidx], s_bases[wv][r], s_consts, vlo, vhi);
+                u128s *dst = (u128s *)(out + coff + sidx);
+                dst[0] = vlo; dst[1] = vhi;
+            }
+        }
+        if (my_lit == ~0ull && n > 64 && n <= 128) {                  // leftovers: lane = record
+            for (uint32_t sidx = 64; sidx < n; sidx++) {
+                u128s vlo, vhi; eval_cell(s_slots[my_sbase + sidx], s_bases[wv][lane], s_consts, vlo, vhi);
+                u128s *dst = (u128s *)(out + my_coff + sidx);
+                dst[0] = vlo; dst[1] = vhi;
+            }
+        }
+    }
+}
+
+static int expand_variant() { static int v = -1; if (v < 0) { const char *e = getenv("H2W_EXPAND_VARIANT"); v = e ? atoi(e) : 0; } return v; }
+
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
     if (A.nrec == 0 || nproofs == 0) return;
+    const int TILE_RECS = expand_variant() == 64 ? 64 : (expand_variant() == 1 || expand_variant() == 2) ? 64 : 32;
     uint64_t ntiles = (A.nrec + TILE_RECS - 1) / TILE_RECS;
+    { static int ov = -2; if (ov == -2) { const char *e = getenv("H2W_EXPAND_BLOCKS"); ov = e ? atoi(e) : -1; } if (ov > 0) grid_x = (int)((uint64_t)ov / nproofs) + 1; }
     uint64_t gx = (uint64_t)grid_x; if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)nproofs);
-    hipLaunchKernelGGL(expand_kernel, grid, dim3(EXPAND_THREADS), 0, stream, A);
+    if (expand_variant() == 2) hipLaunchKernelGGL(expand_kernel_r, grid, dim3(EXPAND_THREADS), 0, stream, A);
+    else if (expand_variant() == 1) hipLaunchKernelGGL(expand_kernel_w, grid, dim3(EXPAND_THREADS), 0, stream, A);
+    else if (expand_variant() == 11) hipLaunchKernelGGL((expand_kernel_t<1, 32, 5>), grid, dim3(EXPAND_THREADS), 0, stream, A);
+    else if (expand_variant() == 12) hipLaunchKernelGGL((expand_kernel_t<2, 32, 5>), grid, dim3(EXPAND_THREADS), 0, stream, A);
+    else if (expand_variant() == 64) hipLaunchKernelGGL((expand_kernel_t<0, 64, 6>), grid, dim3(EXPAND_THREADS), 0, stream, A);
+    else hipLaunchKernelGGL((expand_kernel_t<0, 32, 5>), grid, dim3(EXPAND_THREADS), 0, stream, A);
 }
 
 }  // namespace h2w

@@ -187,7 +187,7 @@ template <class Sink> struct ValBackend {
         if (!cfg.split_bn) return false;
         fr_t *u = cfg.units + 4 * unit_idx; unit_idx++;
         for (int i = 0; i < 4; i++) u[i] = st[i];
-        bn_poseidon_native(st, cfg.consts_mont, cfg.P);
+        sink.bn_native(st, cfg.consts_mont, cfg.P);
         sink.skip(0, cfg.bn_perm_cells + (zero_cached ? 0 : 1)); zero_cached = true;
         return true;
     }
@@ -222,6 +222,7 @@ struct DevSink {
     HF void bn_perm_end(bool) {}
     HF void note_load(uint64_t, int) {}
     HF bool coop_load_proof(const ValCfg &) { return false; }
+    HF void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
 };
 
 }  // namespace h2w
