@@ -34,6 +34,12 @@ struct PlanSink {
     void note_load(uint64_t w, int kind) { LoadItem it; it.word = (uint32_t)w; it.kind = (uint32_t)kind; it.rec = nrec; it.cell = cell_off; items->push_back(it); }
     bool coop_load_proof(const ValCfg &) { return false; }
     void bn_native(fr_t *, const h2w_poseidon_consts_t *, const FrParams &) {}
+    bool unit_writer() const { return false; }
+    int coop_lanes() { return 1; }
+    int coop_lane() { return 0; }
+    uint64_t lane_bcast(uint64_t v, int) { return v; }
+    void begin_lane_cells(uint64_t, bool) {}
+    void end_lane_cells(uint64_t) {}
     void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
     void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
     void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta->push_back(meta_pack((uint32_t)t, cell_off)); nrec++; cell_off += (uint64_t)tt->ncells(t); }
@@ -58,7 +64,7 @@ struct BatchArgs {
     DevCB *cbs; uint32_t *status;
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
     StrandTable st; FrParams P;
-    int nproofs, role_base;
+    int nproofs, role_base, dbg_skip_perm;
     fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
 };
@@ -84,11 +90,9 @@ __global__ __launch_bounds__(64) void k_prologue(BatchArgs A) {
 // one wavefront per proof: wave-uniform gadget code, Goldilocks Poseidon split over 12 lanes (coop.h)
 __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
     __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
-    __shared__ uint64_t s_k[GLP_CONST_WORDS];
-    for (int i = threadIdx.x; i < GLP_CONST_WORDS; i += 64) s_k[i] = reinterpret_cast<const uint64_t *>(A.consts)[i];
-    __syncthreads();
+    stage_glp_consts(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
-    CoopSink sink; sink.kl = reinterpret_cast<const h2w_poseidon_consts_t *>(s_k); sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm;
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
@@ -98,14 +102,12 @@ __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
 // Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot
 __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
     __builtin_amdgcn_s_setprio(3);
-    __shared__ uint64_t s_k[GLP_CONST_WORDS];
-    for (int i = threadIdx.x; i < GLP_CONST_WORDS; i += 64) s_k[i] = reinterpret_cast<const uint64_t *>(A.consts)[i];
-    __syncthreads();
+    stage_glp_consts(A.consts, threadIdx.x, 64);
     const int idx = blockIdx.x, nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    CoopSink sink; sink.kl = reinterpret_cast<const h2w_poseidon_consts_t *>(s_k); sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x;
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
@@ -490,6 +492,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
     A.bn_perm_cells = 4032; A.role_base = 0;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e && e[0] == '1'; } A.dbg_skip_perm = dbg; }
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;

@@ -17,15 +17,45 @@ constexpr int GLP_RECS_PARTIAL = 12 + 1 + 121 + N_PARTIAL_ROUNDS * GLP_RECS_PART
 constexpr int GLP_CONST_WORDS = 360 + 12 + 12 + 12 + 22 + 121 + 242 + 242;   // u64 words of the Goldilocks block of h2w_poseidon_consts_t
 constexpr int GLP_RECS = 2 * HALF_N_FULL_ROUNDS * GLP_RECS_FULL + GLP_RECS_PARTIAL;   // 2604
 
+// The cooperating block is ONE wavefront: its LDS operations execute in program order and its lanes run in lockstep, so
+// lanes exchange the Poseidon state through LDS with no barrier.  __syncthreads() would also wait for vmcnt(0), i.e. for
+// every outstanding record STORE to be acknowledged by memory (~1-2 us) at each of the ~90 exchange points of a
+// permutation; this waits for LDS only.
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// Goldilocks-Poseidon round constants + MDS, staged in LDS by the cooperative kernels (stage_glp_consts) and read with
+// ds_read (a namespace-scope __shared__ array keeps the LDS address space; a pointer member would decay to flat).
+__shared__ uint64_t s_glp_k[GLP_CONST_WORDS];
+constexpr int KO_ARC = 0, KO_CIRC = 360, KO_DIAG = 372, KO_FIRST = 384, KO_PRC = 396, KO_INIT = 418, KO_WHAT = 539, KO_VS = 781;
+static_assert(KO_VS + 242 == GLP_CONST_WORDS, "Goldilocks constant block layout");
+__device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k, int tid, int nthreads) {
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(k);
+    for (int i = tid; i < GLP_CONST_WORDS; i += nthreads) s_glp_k[i] = g_load_u64(src + i);
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint64_t gl_add_c(uint64_t x, uint64_t y) {   // canonical x + y mod p
+    uint64_t t = x + y;
+    if (t < x || t >= GL_P) t -= GL_P;
+    return t;
+}
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) { return __shfl_up(v, d, 64); }
+
 struct CoopSink {
     static constexpr bool kCoop = true;
-    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane;
-    const h2w_poseidon_consts_t *kl;   // Goldilocks-Poseidon round constants + MDS staged in LDS by the kernel (first GLP_CONST_WORDS u64 valid)
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; int dbg_skip_perm = 0;
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-        if (lane == 0) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec] = r; }
+        if (lane == 0) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
-    __device__ __forceinline__ void cell(const fr_t &v) { if (lane == 0) out[cell_off] = v; cell_off++; }
+    bool lane_mode = false, lane_on = false;     // lane_mode: every enabled lane writes cells at its OWN offset (coop_decompose_hashes)
+    __device__ __forceinline__ void cell(const fr_t &v) { if (lane_mode ? lane_on : lane == 0) g_store_fr(out + cell_off, v); cell_off++; }
+    __device__ bool unit_writer() const { return lane == 0; }
+    __device__ int coop_lanes() { return 64; }
+    __device__ int coop_lane() { return lane; }
+    __device__ uint64_t lane_bcast(uint64_t v, int src) { return __shfl(v, src, 64); }
+    __device__ void begin_lane_cells(uint64_t off, bool on) { cell_off = off; lane_mode = true; lane_on = on; }
+    __device__ void end_lane_cells(uint64_t off) { cell_off = off; lane_mode = false; }
     __device__ __forceinline__ void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     __device__ void merkle_begin(int, int, bool, uint64_t) {}
     __device__ void merkle_end(int, int, bool) {}
@@ -38,28 +68,34 @@ struct CoopSink {
     // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
     __device__ __noinline__ bool coop_load_proof(const ValCfg &cfg) {
         for (uint32_t i = lane; i < cfg.n_load_items; i += 64) {
-            const LoadItem it = cfg.load_items[i]; const uint64_t *w = cfg.proof + it.word;
-            rec_t r; r.a = w[0]; r.b = 0; r.c = 0; r.d = 0;
-            if (it.kind <= 1) recs[it.rec] = r;
-            else if (it.kind == 2) { r.b = w[1]; r.c = w[2]; r.d = w[3]; recs[it.rec] = r; }
-            else { fr_t v; v.l[0] = w[0]; v.l[1] = w[1]; v.l[2] = w[2]; v.l[3] = w[3]; out[it.cell] = v; }
+            const uint64_t *ip = reinterpret_cast<const uint64_t *>(cfg.load_items + i);
+            const uint64_t wk = g_load_u64(ip), irec = g_load_u64(ip + 1), icell = g_load_u64(ip + 2);
+            const uint32_t word = (uint32_t)wk, kind = (uint32_t)(wk >> 32);
+            const uint64_t *w = cfg.proof + word; const uint64_t w0 = g_load_u64(w);
+            if (kind <= 1) g_store_rec(recs + irec, w0, 0, 0, 0);
+            else if (kind == 2) g_store_rec(recs + irec, w0, g_load_u64(w + 1), g_load_u64(w + 2), g_load_u64(w + 3));
+            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); g_store_fr(out + icell, v); }
         }
         nrec += cfg.load_nrec; cell_off += cfg.load_ncell;
         return true;
     }
 
     __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
-        const h2w_poseidon_consts_t *k = kl;
         __shared__ uint64_t s_a[SPONGE_WIDTH], s_b[SPONGE_WIDTH];
         rec_t *R = recs + nrec;
-        const int l = lane;
-        auto W = [&](int idx, uint64_t A, uint64_t B, uint64_t C) { rec_t r; r.a = A; r.b = B; r.c = C; r.d = 0; R[idx] = r; };
+        if (dbg_skip_perm) {   // timing-only diagnostic (H2W_DBG_SKIP_PERM=1): advance the counters, skip the arithmetic
+            const uint64_t nG0 = ncells[T_GLOP], nKA0 = ncells[T_KA_GLOP];
+            nrec += GLP_RECS; cell_off += 2 * HALF_N_FULL_ROUNDS * (12 * nKA0 + 48 * nG0 + 12 + 12 * (1 + 13 * nKA0)) + 12 * nKA0 + 12 + 121 * nKA0 + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG0 + nKA0 + nKA0 + 11 * nKA0 + 12 + 11 * nKA0);
+            return;
+        }
+        const int l = lane, grp13 = lane / 13, idx13 = lane % 13;
+        auto W = [&](int idx, uint64_t A, uint64_t B, uint64_t C) { g_store_rec(R + idx, A, B, C, 0); };
         if (l < SPONGE_WIDTH) s_a[l] = st[l];
-        __syncthreads();
+        wave_sync();
         int base = 0, round_ctr = 0;
         auto full_round = [&]() {
             if (l < SPONGE_WIDTH) {
-                uint64_t x = s_a[l]; const uint64_t rc = k->all_round_constants[l + SPONGE_WIDTH * round_ctr];
+                uint64_t x = s_a[l]; const uint64_t rc = s_glp_k[KO_ARC + l + SPONGE_WIDTH * round_ctr];
                 W(base + l, rc, 1, x); x = gl_add(x, rc);                                   // constant_layer
                 const int sb = base + 12 + 4 * l;                                            // sbox_monomial: x^7
                 const uint64_t x2 = gl_mul(x, x); W(sb, x, x, 0);
@@ -68,41 +104,53 @@ struct CoopSink {
                 const uint64_t x7 = gl_mul(x6, x); W(sb + 3, x6, x, 0);
                 s_b[l] = x7;
             }
-            __syncthreads();
+            wave_sync();
             const int mb = base + 60;                                                        // mds_layer
+            // 12 rows x 13 terms: res_i = (sum_{j<=i} c_j v_j) mod p.  Products in parallel (lane = row_in_pass*13 + i, 4 rows
+            // per pass), then a segmented inclusive scan over each 13-lane group: 1 product + 4 adds deep instead of 13 mul-adds.
             if (l == 0) W(mb, 0, 0, 0);
-            if (l < SPONGE_WIDTH) {
-                const int rb = mb + 1 + 14 * l; W(rb, 0, 0, 0);
-                uint64_t res = 0;
-                for (int i = 0; i < SPONGE_WIDTH; i++) {
-                    const uint64_t c = k->mds_circ[i], v = s_b[(i + l) % SPONGE_WIDTH];
-                    W(rb + 1 + i, c, v, res); res = gl_muladd(c, v, res);
+            uint64_t rowres = 0;
+#pragma unroll
+            for (int pass = 0; pass < 3; pass++) {
+                const int rr = pass * 4 + grp13;
+                uint64_t c = 0, v = 0, x = 0;
+                if (l < 52) {
+                    if (idx13 < 12) { c = s_glp_k[KO_CIRC + idx13]; int vi = idx13 + rr; if (vi >= 12) vi -= 12; v = s_b[vi]; }
+                    else { c = s_glp_k[KO_DIAG + rr]; v = s_b[rr]; }
+                    x = gl_mul(c, v);
                 }
-                const uint64_t c = k->mds_diag[l], v = s_b[l];
-                W(rb + 13, c, v, res); res = gl_muladd(c, v, res);
-                s_a[l] = res;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) { const uint64_t y = shfl_up64(x, d); if (idx13 >= d) x = gl_add_c(x, y); }
+                uint64_t prev = shfl_up64(x, 1); if (idx13 == 0) prev = 0;
+                if (l < 52) {
+                    const int rb = mb + 1 + 14 * rr;
+                    if (idx13 == 0) W(rb, 0, 0, 0);
+                    W(rb + 1 + idx13, c, v, prev);
+                    if (idx13 == 12) rowres = x;
+                }
+                if (l < 52 && idx13 == 12) s_a[rr] = rowres;
             }
-            __syncthreads();
+            wave_sync();
             base += GLP_RECS_FULL; round_ctr++;
         };
         for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round();
         // ---- partial rounds (hash/poseidon/permutation.rs:216-239)
         if (l < SPONGE_WIDTH) {                                                              // partial_first_constant_layer
-            const uint64_t x = s_a[l], c = k->fast_partial_first_round_constant[l];
+            const uint64_t x = s_a[l], c = s_glp_k[KO_FIRST + l];
             W(base + l, c, 1, x); s_b[l] = gl_add(x, c);
         }
-        __syncthreads();
+        wave_sync();
         base += 12;
         if (l == 0) { W(base, 0, 0, 0); s_a[0] = s_b[0]; }                                   // mds_partial_layer_init
         else if (l < SPONGE_WIDTH) {
             uint64_t res = 0;
             for (int r = 1; r < SPONGE_WIDTH; r++) {
-                const uint64_t t = k->fast_partial_round_initial_matrix[r - 1][l - 1], v = s_b[r];
+                const uint64_t t = s_glp_k[KO_INIT + (r - 1) * 11 + (l - 1)], v = s_b[r];
                 W(base + 1 + (r - 1) * 11 + (l - 1), t, v, res); res = gl_muladd(t, v, res);
             }
             s_a[l] = res;
         }
-        __syncthreads();
+        wave_sync();
         base += 122;
         for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
             if (l == 0) {
@@ -111,30 +159,36 @@ struct CoopSink {
                 const uint64_t x4 = gl_mul(x2, x2); W(base + 1, x2, x2, 0);
                 const uint64_t x6 = gl_mul(x4, x2); W(base + 2, x4, x2, 0);
                 const uint64_t x7 = gl_mul(x6, x); W(base + 3, x6, x, 0);
-                const uint64_t c = k->fast_partial_round_constants[r];
+                const uint64_t c = s_glp_k[KO_PRC + r];
                 W(base + 4, c, 1, x7); s_a[0] = gl_add(x7, c);
             }
-            __syncthreads();
+            wave_sync();
             const uint64_t s0 = s_a[0];                                                      // mds_partial_layer_fast
-            if (l == 0) {
-                const uint64_t m00 = k->mds_circ[0] + k->mds_diag[0];
-                W(base + 5, m00, s0, 0); uint64_t d = gl_mul(m00, s0);
-                for (int i = 1; i < SPONGE_WIDTH; i++) { const uint64_t t = k->fast_partial_round_w_hats[r][i - 1], v = s_a[i]; W(base + 5 + i, t, v, d); d = gl_muladd(t, v, d); }
-                W(base + 17, 0, 0, 0);
-                s_b[0] = d;
-            } else if (l < SPONGE_WIDTH) {
-                const uint64_t t = k->fast_partial_round_vs[r][l - 1], v = s_a[l];
-                W(base + 17 + l, t, s0, v); s_b[l] = gl_muladd(t, s0, v);
+            {   // d = m00*s0 + sum_i w_hat_i * st_i as an inclusive scan over lanes 0..11 (records need every partial sum)
+                uint64_t t = 0, v = 0, x = 0;
+                if (l == 0) { t = s_glp_k[KO_CIRC] + s_glp_k[KO_DIAG]; v = s0; }
+                else if (l < SPONGE_WIDTH) { t = s_glp_k[KO_WHAT + r * 11 + (l - 1)]; v = s_a[l]; }
+                if (l < SPONGE_WIDTH) x = gl_mul(t, v);
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) { const uint64_t y = shfl_up64(x, d); if (l >= d) x = gl_add_c(x, y); }
+                uint64_t prev = shfl_up64(x, 1); if (l == 0) prev = 0;
+                if (l < SPONGE_WIDTH) W(base + 5 + l, t, v, prev);
+                if (l == 0) W(base + 17, 0, 0, 0);
+                if (l == SPONGE_WIDTH - 1) s_b[0] = x;
+                if (l > 0 && l < SPONGE_WIDTH) {
+                    const uint64_t tv = s_glp_k[KO_VS + r * 11 + (l - 1)];
+                    W(base + 17 + l, tv, s0, v); s_b[l] = gl_muladd(tv, s0, v);
+                }
             }
-            __syncthreads();
+            wave_sync();
             if (l < SPONGE_WIDTH) s_a[l] = s_b[l];
-            __syncthreads();
+            wave_sync();
             base += GLP_RECS_PARTIAL_ROUND;
         }
         round_ctr += N_PARTIAL_ROUNDS;
         for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round();
         for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = s_a[i];
-        __syncthreads();
+        wave_sync();
         const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
         const uint64_t full_cells = 12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA);
         const uint64_t part_cells = 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
@@ -151,10 +205,16 @@ struct QuadSink {
     static constexpr bool kCoop = false;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4;
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-        if (l4 == 0) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec] = r; }
+        if (l4 == 0) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
-    __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) out[cell_off] = v; cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) g_store_fr(out + cell_off, v); cell_off++; }
+    __device__ bool unit_writer() const { return l4 == 0; }
+    __device__ int coop_lanes() { return 1; }
+    __device__ int coop_lane() { return 0; }
+    __device__ uint64_t lane_bcast(uint64_t v, int) { return v; }
+    __device__ void begin_lane_cells(uint64_t, bool) {}
+    __device__ void end_lane_cells(uint64_t) {}
     __device__ __forceinline__ void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     __device__ void merkle_begin(int, int, bool, uint64_t) {}
     __device__ void merkle_end(int, int, bool) {}

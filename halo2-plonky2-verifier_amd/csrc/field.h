@@ -21,6 +21,19 @@
 namespace h2w {
 
 typedef unsigned __int128 u128;
+
+// Explicit global-address-space accesses.  Pointers that travel through structs / noinline calls lose their address
+// space and hipcc falls back to flat_load / flat_store, which count on BOTH vmcnt and lgkmcnt: every dependent flat
+// load then waits for all outstanding record stores (s_waitcnt vmcnt(0) lgkmcnt(0)) — ~1-2 us per exchange.  These
+// helpers emit global_load / global_store.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+#define H2W_GLOAD64(p) (*(const ::h2w::gu64_t *)(p))
+#define H2W_GSTORE64(p, v) (*(::h2w::gu64_t *)(p) = (v))
+#else
+#define H2W_GLOAD64(p) (*(const unsigned long long *)(p))
+#define H2W_GSTORE64(p, v) (*(unsigned long long *)(p) = (v))
+#endif
 typedef h2w_fr_t fr_t;
 
 constexpr uint64_t GL_P = 0xFFFFFFFF00000001ULL;
@@ -221,6 +234,15 @@ HDN inline fr_t fr_inv(const fr_t &a, const FrParams &P) {
     return fr_pow(a, e, P);
 }
 HD fr_t fr_pow2(int k) { fr_t r = fr_zero(); r.l[k >> 6] = 1ULL << (k & 63); return r; }
+HD void g_store_fr(fr_t *p, const fr_t &v) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    H2W_GSTORE64(q, v.l[0]); H2W_GSTORE64(q + 1, v.l[1]); H2W_GSTORE64(q + 2, v.l[2]); H2W_GSTORE64(q + 3, v.l[3]);
+}
+HD fr_t g_load_fr(const fr_t *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    fr_t v; v.l[0] = H2W_GLOAD64(q); v.l[1] = H2W_GLOAD64(q + 1); v.l[2] = H2W_GLOAD64(q + 2); v.l[3] = H2W_GLOAD64(q + 3); return v;
+}
+HD uint64_t g_load_u64(const uint64_t *p) { return H2W_GLOAD64(p); }
 HD uint64_t fr_bits(const fr_t &v, int lo, int width) {
     if (lo >= 256) return 0;
     int w = lo >> 6, sh = lo & 63;

@@ -17,6 +17,10 @@
 namespace h2w {
 
 struct rec_t { uint64_t a, b, c, d; };
+HD void g_store_rec(rec_t *p, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    H2W_GSTORE64(q, a); H2W_GSTORE64(q + 1, b); H2W_GSTORE64(q + 2, c); H2W_GSTORE64(q + 3, d);
+}
 
 // base indices
 enum { B_A = 0, B_B, B_C, B_D, B_V, B_X0, B_X0P, B_X0PP, B_X1, B_X1P, B_X1PP, B_COUNT };

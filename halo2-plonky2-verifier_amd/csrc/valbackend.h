@@ -78,9 +78,9 @@ template <class Sink> struct ValBackend {
 
     // ---------------------------------------------------------------- small native templates: direct cells
     HF fr_t inv_small(const fr_t &x) {
-        if ((x.l[1] | x.l[2] | x.l[3]) == 0 && x.l[0] < (uint64_t)INV_TAB) return cfg.inv_pos[x.l[0]];
+        if ((x.l[1] | x.l[2] | x.l[3]) == 0 && x.l[0] < (uint64_t)INV_TAB) return g_load_fr(cfg.inv_pos + x.l[0]);
         fr_t nx = fr_neg(x);
-        if ((nx.l[1] | nx.l[2] | nx.l[3]) == 0 && nx.l[0] < (uint64_t)INV_TAB) return cfg.inv_neg[nx.l[0]];
+        if ((nx.l[1] | nx.l[2] | nx.l[3]) == 0 && nx.l[0] < (uint64_t)INV_TAB) return g_load_fr(cfg.inv_neg + nx.l[0]);
         return fr_inv(x, cfg.P);
     }
     HNI Gl select(Gl a, Gl b, Bool sel) {      // [a-b, 1, b, a, b, sel, a-b, out]
@@ -167,32 +167,47 @@ template <class Sink> struct ValBackend {
         for (int i = 0; i < 5; i++) range_check(out[i], 56);
     }
     // ---------------------------------------------------------------- proof wires (flat layout, verifier.h ProofLayout)
-    HF Gl proof_gl(uint64_t w) { return cfg.proof[w]; }
+    HF uint64_t pw(uint64_t w) { return g_load_u64(cfg.proof + w); }
+    HF Gl proof_gl(uint64_t w) { return pw(w); }
     HF HashW<ValBackend> proof_hash(uint64_t w) {
         HashW<ValBackend> h;
-        if (cfg.mode == 0) { for (int i = 0; i < 4; i++) h.e[i] = cfg.proof[w + i]; h.f = fr_zero(); }
-        else { for (int i = 0; i < 4; i++) { h.f.l[i] = cfg.proof[w + i]; h.e[i] = 0; } }
+        if (cfg.mode == 0) { for (int i = 0; i < 4; i++) h.e[i] = pw(w + i); h.f = fr_zero(); }
+        else { for (int i = 0; i < 4; i++) { h.f.l[i] = pw(w + i); h.e[i] = 0; } }
         return h;
     }
     HF bool coop_load_proof() { return sink.coop_load_proof(cfg); }
-    HF void load_proof_gl(uint64_t w) { sink.note_load(w, 0); gl_witness(cfg.proof[w]); }
-    HF void load_proof_gl_nocheck(uint64_t w) { sink.note_load(w, 1); sink.rec(T_CONST1, cfg.proof[w], 0, 0, 0); }
+    HF void load_proof_gl(uint64_t w) { sink.note_load(w, 0); gl_witness(pw(w)); }
+    HF void load_proof_gl_nocheck(uint64_t w) { sink.note_load(w, 1); sink.rec(T_CONST1, pw(w), 0, 0, 0); }
     HF void load_proof_hash(uint64_t w) {
         sink.note_load(w, cfg.mode == 0 ? 2 : 3);
-        if (cfg.mode == 0) sink.rec(T_CONST4, cfg.proof[w], cfg.proof[w + 1], cfg.proof[w + 2], cfg.proof[w + 3]);
-        else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = cfg.proof[w + i]; cell(v); }
+        if (cfg.mode == 0) sink.rec(T_CONST4, pw(w), pw(w + 1), pw(w + 2), pw(w + 3));
+        else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = pw(w + i); cell(v); }
     }
     // ---------------------------------------------------------------- BN254 permutation units
     HF bool bn_perm_unit(Fr *st, const h2w_poseidon_consts_t *) {
         if (!cfg.split_bn) return false;
         fr_t *u = cfg.units + 4 * unit_idx; unit_idx++;
-        for (int i = 0; i < 4; i++) u[i] = st[i];
+        if (sink.unit_writer()) for (int i = 0; i < 4; i++) g_store_fr(u + i, st[i]);
         sink.bn_native(st, cfg.consts_mont, cfg.P);
         sink.skip(0, cfg.bn_perm_cells + (zero_cached ? 0 : 1)); zero_cached = true;
         return true;
     }
     HF void bn_perm_begin() { sink.bn_perm_begin(zero_cached); }
     HF void bn_perm_end() { sink.bn_perm_end(zero_cached); unit_idx++; }
+    // ---------------------------------------------------------------- cooperative cap decomposition (see Verifier::observe_cap)
+    HF int coop_lanes() { return sink.coop_lanes(); }
+    HF Gl lane_bcast(Gl v, int src) { return sink.lane_bcast(v, src); }
+    HF void coop_decompose_hashes(uint64_t w0, int n, Gl *limbs) {
+        const int me = sink.coop_lane();
+        const uint64_t cell0 = sink.cell_off;                       // RangeChip::decompose_le(x, 56, 5): 13 + 5 range checks
+        const int L = cfg.L, nl = (56 + L - 1) / L, rem = 56 % L;
+        const uint64_t per = 13 + 5ull * ((nl > 1 ? 1 + 3 * (nl - 1) : 0) + (rem ? 4 : 0));
+        sink.begin_lane_cells(cell0 + per * (uint64_t)me, me < n);
+        Fr x = fr_zero();
+        if (me < n) for (int i = 0; i < 4; i++) x.l[i] = pw(w0 + 4ull * me + i);
+        decompose_le_56_5(x, limbs);
+        sink.end_lane_cells(cell0 + per * (uint64_t)n);
+    }
     // ---------------------------------------------------------------- strand hooks
     HF bool merkle_split(int q, int kind) {
         if (!cfg.split) return false;
@@ -211,8 +226,8 @@ struct DevSink {
     static constexpr bool kCoop = false;
     HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells;
-    HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { rec_t r; r.a = a; r.b = b; r.c = c; r.d = d; recs[nrec++] = r; cell_off += ncells[t]; }
-    HF void cell(const fr_t &v) { out[cell_off++] = v; }
+    HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }
+    HF void cell(const fr_t &v) { g_store_fr(out + cell_off, v); cell_off++; }
     HF void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     HF void merkle_begin(int, int, bool, uint64_t) {}
     HF void merkle_end(int, int, bool) {}
@@ -223,6 +238,12 @@ struct DevSink {
     HF void note_load(uint64_t, int) {}
     HF bool coop_load_proof(const ValCfg &) { return false; }
     HF void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
+    HF bool unit_writer() const { return true; }
+    HF int coop_lanes() { return 1; }
+    HF int coop_lane() { return 0; }
+    HF uint64_t lane_bcast(uint64_t v, int) { return v; }
+    HF void begin_lane_cells(uint64_t, bool) {}
+    HF void end_lane_cells(uint64_t) {}
 };
 
 }  // namespace h2w

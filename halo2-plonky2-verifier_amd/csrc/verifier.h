@@ -78,7 +78,20 @@ template <class B> struct Verifier {
         }
         for (int i = 0; i < s.n_pis; i++, w++) load_gl(w);                                      // public inputs (:285-288)
     }
-    HF void observe_cap(ChallengerChip<B> &ch, uint64_t w0) { for (int i = 0; i < d.cap_size; i++) ch.observe_hash(be.proof_hash(w0 + 4ull * i)); } // challenger/mod.rs:65-74
+    HF void observe_cap(ChallengerChip<B> &ch, uint64_t w0) {                                       // challenger/mod.rs:65-74
+        if (s.hash_mode == 1 && be.coop_lanes() > 1) {
+            // BN254 caps on a cooperating wavefront: lane j decomposes hash j (its 68 cells are independent of the others'),
+            // then the 5 limbs of every hash are handed to all lanes in order (the sponge buffer is wave-uniform)
+            typename B::Gl limbs[5];
+            for (int base = 0; base < d.cap_size; base += be.coop_lanes()) {
+                const int n = d.cap_size - base < be.coop_lanes() ? d.cap_size - base : be.coop_lanes();
+                be.coop_decompose_hashes(w0 + 4ull * base, n, limbs);
+                for (int j = 0; j < n; j++) for (int t = 0; t < 5; t++) ch.observe_element(be.lane_bcast(limbs[t], j));
+            }
+            return;
+        }
+        for (int i = 0; i < d.cap_size; i++) ch.observe_hash(be.proof_hash(w0 + 4ull * i));
+    }
     // openings in to_fri_openings() order (stark/mod.rs:48-69): zeta batch = local, perm_zs, quotient ; zeta_next batch = next, perm_zs_next
     HF uint64_t zeta_word(int i) const {
         uint64_t o = pl.openings;
