@@ -24,6 +24,14 @@ typedef ChallengeBlock<DevB> DevCB;
 typedef ValBackend<CoopSink> CoopB;
 typedef ValBackend<QuadSink> QuadB;   // same wire types as DevB: ChallengeBlock layouts coincide
 
+// PoseidonBN254 constants for the unit kernel, canonical [0] and Montgomery form [1], in CONSTANT address space:
+// wave-uniform reads become scalar loads (lgkmcnt), which — unlike vector loads — do not queue behind the kernel's own
+// outstanding cell stores on vmcnt.  One table per device context; re-uploaded on the stream when a plan with
+// different constants runs (g_const_owner).
+struct BnConsts { h2w_fr_t c[88], s[392], m[4][4], p[4][4]; };
+__constant__ BnConsts c_bn[2];
+static const void *g_const_owner = nullptr;
+
 struct PlanSink {
     static constexpr bool kCoop = false;
     void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
@@ -206,24 +214,25 @@ __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
 // flush them as whole 128-B lines (4 permutations x 512 contiguous bytes per store instruction) instead of 64 scattered
 // 32-byte stores; all lanes of the wave are in lockstep (same cell count), which the one odd unit with the cached
 // load_zero cell would break, so that unit runs in its own launch with STAGED = false.
-constexpr int BN_CH = 16;
+constexpr int BN_CH = 8;
 constexpr int BN_ROW = 64 * 32 + 32;   // bytes per staged cell row
 template <bool STAGED> struct BnEmit {
-    fr_t *out; const h2w_poseidon_consts_t *kc, *km; uint64_t ninv; fr_t r2;
+    fr_t *out; uint64_t ninv; fr_t r2;
     char *lds; int lane, cnt;
     __device__ __forceinline__ void flush() {
         typedef unsigned long long ull; struct __attribute__((aligned(16))) q16 { ull x, y; };
         __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
         const unsigned long long mydst = (unsigned long long)out;
 #pragma unroll 4
-        for (int it = 0; it < 16; it++) {
+        for (int it = 0; it < 16; it++) {   // per store instruction: 4 permutations x 256 contiguous bytes (8 cells)
             const int P = it * 4 + (lane >> 4), k = (lane & 15) >> 1, h = lane & 1;
             const unsigned long long d = __shfl(mydst, P, 64);
-            // lane handles 16 B: cell k and cell k+8 of permutation P (two stores: 2 x 256 B per permutation each)
-            const q16 v0 = *reinterpret_cast<const q16 *>(lds + k * BN_ROW + P * 32 + h * 16);
-            const q16 v1 = *reinterpret_cast<const q16 *>(lds + (k + 8) * BN_ROW + P * 32 + h * 16);
-            *reinterpret_cast<q16 *>(d + (unsigned long long)(k * 32 + h * 16)) = v0;
-            *reinterpret_cast<q16 *>(d + (unsigned long long)((k + 8) * 32 + h * 16)) = v1;
+#pragma unroll
+            for (int kk = 0; kk < BN_CH; kk += 8) {
+                const q16 v0 = *reinterpret_cast<const q16 *>(lds + (k + kk) * BN_ROW + P * 32 + h * 16);
+                unsigned long long *g = reinterpret_cast<unsigned long long *>(d + (unsigned long long)((k + kk) * 32 + h * 16));
+                H2W_GSTORE64(g, v0.x); H2W_GSTORE64(g + 1, v0.y);
+            }
         }
         out += BN_CH; cnt = 0;
     }
@@ -242,7 +251,8 @@ template <bool STAGED> struct BnEmit {
         return x5;
     }
     __device__ __forceinline__ void ark(fr_t *s, int it) {
-        for (int i = 0; i < 4; i++) { const fr_t c = kc->bn_c[it + i]; put(c); put(s[i]); put(c); put64(1); s[i] = fr_add(s[i], c); put(s[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const fr_t c = c_bn[0].c[it + i]; put(c); put(s[i]); put(c); put64(1); s[i] = fr_add(s[i], c); put(s[i]); }
     }
     __device__ __forceinline__ fr_t mul_add(const fr_t &c, const fr_t &cm, const fr_t &x, const fr_t &acc) {   // [acc, c, x, c*x+acc]
         const fr_t v = fr_add(fr_mont_mul(x, cm, ninv), acc);
@@ -252,34 +262,45 @@ template <bool STAGED> struct BnEmit {
     __device__ __forceinline__ void mix(fr_t *s, const h2w_fr_t (*mc)[4], const h2w_fr_t (*mm)[4], bool &zero_cached) {
         if (!zero_cached) { put64(0); zero_cached = true; }
         fr_t ns[4];
-        for (int i = 0; i < 4; i++) { fr_t acc = fr_zero(); for (int j = 0; j < 4; j++) acc = mul_add(mc[j][i], mm[j][i], s[j], acc); ns[i] = acc; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            fr_t acc = fr_zero();
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = mul_add(mc[j][i], mm[j][i], s[j], acc);
+            ns[i] = acc;
+        }
+#pragma unroll
         for (int i = 0; i < 4; i++) s[i] = ns[i];
     }
-    __device__ void permute(fr_t *s, bool zero_cached) {
+    __device__ __forceinline__ void permute(fr_t *s, bool zero_cached) {
         ark(s, 0);
         for (int half = 0; half < 2; half++) {
             if (half == 1) {   // partial rounds (:83-110)
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
                     s[0] = exp5(s[0]);
-                    const fr_t c = kc->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r];
+                    const fr_t c = c_bn[0].c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r];
                     put(c); put(s[0]); put(c); put64(1); s[0] = fr_add(s[0], c); put(s[0]);
                     fr_t ns0 = fr_zero();
-                    for (int j = 0; j < 4; j++) { const int ix = (BN_WIDTH * 2 - 1) * r + j; put(kc->bn_s[ix]); ns0 = mul_add(kc->bn_s[ix], km->bn_s[ix], s[j], ns0); }
-                    for (int kk = 1; kk < 4; kk++) { const int ix = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1; put(kc->bn_s[ix]); s[kk] = mul_add(kc->bn_s[ix], km->bn_s[ix], s[0], s[kk]); }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int ix = (BN_WIDTH * 2 - 1) * r + j; put(c_bn[0].s[ix]); ns0 = mul_add(c_bn[0].s[ix], c_bn[1].s[ix], s[j], ns0); }
+#pragma unroll
+                    for (int kk = 1; kk < 4; kk++) { const int ix = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1; put(c_bn[0].s[ix]); s[kk] = mul_add(c_bn[0].s[ix], c_bn[1].s[ix], s[0], s[kk]); }
                     s[0] = ns0;
                 }
             }
             // full_rounds(is_first = half == 0) (:112-160)
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(kc->bn_m[i][j]);
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(kc->bn_p[i][j]);
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(c_bn[0].m[i][j]);
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(c_bn[0].p[i][j]);
             for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
+#pragma unroll
                 for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
                 ark(s, half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
-                mix(s, kc->bn_m, km->bn_m, zero_cached);
+                mix(s, c_bn[0].m, c_bn[1].m, zero_cached);
             }
+#pragma unroll
             for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
-            if (half == 0) { ark(s, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(s, kc->bn_p, km->bn_p, zero_cached); }
-            else mix(s, kc->bn_m, km->bn_m, zero_cached);
+            if (half == 0) { ark(s, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(s, c_bn[0].p, c_bn[1].p, zero_cached); }
+            else mix(s, c_bn[0].m, c_bn[1].m, zero_cached);
         }
     }
 };
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
         const uint64_t zp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (zp < (uint64_t)A.nproofs && A.st.first_zero_unit >= 0) {
             const uint64_t uz = (uint64_t)A.st.first_zero_unit;
-            BnEmit<false> Z; Z.out = A.out + zp * A.cell_stride + A.unit_cell[uz]; Z.kc = A.consts; Z.km = A.consts_mont; Z.ninv = A.P.ninv; Z.r2 = A.P.r2; Z.lds = nullptr; Z.lane = 0; Z.cnt = 0;
+            BnEmit<false> Z; Z.out = A.out + zp * A.cell_stride + A.unit_cell[uz]; Z.ninv = A.P.ninv; Z.r2 = A.P.r2; Z.lds = nullptr; Z.lane = 0; Z.cnt = 0;
             fr_t zs[4]; const fr_t *zin = A.units + (zp * A.unit_stride + uz) * 4;
             for (int i = 0; i < 4; i++) zs[i] = zin[i];
             Z.permute(zs, false);
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
     if (idx >= total) idx = total - 1;                 // tail lanes redo the last unit (identical bytes) to keep the wave in lockstep
     const int p = (int)(idx / nreg); uint64_t u = idx % nreg;
     if (A.st.first_zero_unit >= 0 && u >= (uint64_t)A.st.first_zero_unit) u++;
-    BnEmit<true> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.kc = A.consts; E.km = A.consts_mont; E.ninv = A.P.ninv; E.r2 = A.P.r2;
+    BnEmit<true> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.ninv = A.P.ninv; E.r2 = A.P.r2;
     E.lds = s_stage; E.lane = threadIdx.x; E.cnt = 0;
     fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
     for (int i = 0; i < 4; i++) st[i] = in[i];
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(64) void k_bn_unit_zero(BatchArgs A) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.nproofs || A.st.first_zero_unit < 0) return;
     const uint64_t u = (uint64_t)A.st.first_zero_unit;
-    BnEmit<false> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.kc = A.consts; E.km = A.consts_mont; E.ninv = A.P.ninv; E.r2 = A.P.r2;
+    BnEmit<false> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.ninv = A.P.ninv; E.r2 = A.P.r2;
     E.lds = nullptr; E.lane = 0; E.cnt = 0;
     fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
     for (int i = 0; i < 4; i++) st[i] = in[i];
@@ -342,6 +363,7 @@ struct h2w_plan {
     Derived d; ProofLayout pl;
     uint64_t nrec = 0, ncells = 0, rec_cells = 0;
     LoadItem *d_items = nullptr; uint32_t n_items = 0; uint64_t load_nrec = 0, load_ncell = 0;
+    BnConsts h_bn[2];
     uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
@@ -427,6 +449,8 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             for (int i = 0; i < 88; i++) km->bn_c[i] = fr_mont_mul(consts->bn_c[i], pl->P.r2, pl->P.ninv);
             for (int i = 0; i < 392; i++) km->bn_s[i] = fr_mont_mul(consts->bn_s[i], pl->P.r2, pl->P.ninv);
             for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { km->bn_m[i][j] = fr_mont_mul(consts->bn_m[i][j], pl->P.r2, pl->P.ninv); km->bn_p[i][j] = fr_mont_mul(consts->bn_p[i][j], pl->P.r2, pl->P.ninv); }
+            memcpy(pl->h_bn[0].c, consts->bn_c, sizeof(consts->bn_c)); memcpy(pl->h_bn[0].s, consts->bn_s, sizeof(consts->bn_s)); memcpy(pl->h_bn[0].m, consts->bn_m, sizeof(consts->bn_m)); memcpy(pl->h_bn[0].p, consts->bn_p, sizeof(consts->bn_p));
+            memcpy(pl->h_bn[1].c, km->bn_c, sizeof(km->bn_c)); memcpy(pl->h_bn[1].s, km->bn_s, sizeof(km->bn_s)); memcpy(pl->h_bn[1].m, km->bn_m, sizeof(km->bn_m)); memcpy(pl->h_bn[1].p, km->bn_p, sizeof(km->bn_p));
             hipError_t e1 = hipMalloc((void **)&pl->d_consts_mont, sizeof(h2w_poseidon_consts_t));
             hipError_t e2 = e1 == hipSuccess ? hipMemcpy(pl->d_consts_mont, km, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice) : e1;
             delete km;
@@ -449,6 +473,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
 }
 void h2w_plan_free(h2w_plan *p) {
     if (!p) return;
+    if (g_const_owner == (const void *)p) g_const_owner = nullptr;
     if (p->d_meta) (void)hipFree(p->d_meta);
     if (p->d_unit_cell) (void)hipFree(p->d_unit_cell);
     if (p->d_items) (void)hipFree(p->d_items);
@@ -511,6 +536,10 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         // emit phase starts here: the HBM-bound kernels of successive calls (issued on different streams) run FIFO,
         // so the latency-bound value strands of call k+1 overlap the emit phase of call k instead of all calls phase-locking
         if (p->fifo_emit && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
+        if (g_const_owner != (const void *)p) {   // (re)load the constant-memory tables for this plan, ordered on `stream`
+            H2W_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_bn), p->h_bn, sizeof(p->h_bn), 0, hipMemcpyHostToDevice, stream));
+            g_const_owner = (const void *)p;
+        }
         const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
         const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
         if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64 + zblocks)), dim3(64), 0, stream, A);
