@@ -186,13 +186,13 @@ class Plan:
         return list(st)
 
     def timing(self, back=0):
-        """(prologue ms, strands ms, expansion-kernel ms, total ms) of the batch call `back` calls before the last,
-        from HIP events recorded on the call's stream."""
-        ms = (C.c_float * 4)()
+        """(prologue ms, strands ms, BN254-unit ms, expansion-kernel ms, total ms) of the batch call `back` calls before
+        the last, from HIP events recorded on the call's stream."""
+        ms = (C.c_float * 5)()
         _ck(self.L.h2w_plan_timing(self.p, back, ms), "h2w_plan_timing")
         return tuple(ms)
 
     def last_timing(self):
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 5)()
         _ck(self.L.h2w_plan_last_timing(self.p, ms), "h2w_plan_last_timing")
         return tuple(ms)

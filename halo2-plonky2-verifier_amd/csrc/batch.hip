@@ -216,60 +216,58 @@ __global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
 // load_zero cell would break, so that unit runs in its own launch with STAGED = false.
 constexpr int BN_CH = 8;
 constexpr int BN_ROW = 64 * 32 + 32;   // bytes per staged cell row
+// One out-of-line copy of the Montgomery product (arguments and result in VGPRs, by value): the unit kernel has ~25 call
+// sites and must stay inside the 64 KB instruction cache (fully inlined it was ~400 KB and ran instruction-fetch bound).
+__device__ __attribute__((noinline)) fr_t mont_nv(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }
+__device__ __attribute__((noinline)) void bn_flush(const char *lds, unsigned long long mydst, int lane) {
+    typedef unsigned long long ull; struct __attribute__((aligned(16))) q16 { ull x, y; };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 2
+    for (int it = 0; it < 16; it++) {   // per store instruction: 4 permutations x 256 contiguous bytes (8 cells)
+        const int P = it * 4 + (lane >> 4), k = (lane & 15) >> 1, h = lane & 1;
+        const unsigned long long d = __shfl(mydst, P, 64);
+#pragma unroll
+        for (int kk = 0; kk < BN_CH; kk += 8) {
+            const q16 v0 = *reinterpret_cast<const q16 *>(lds + (k + kk) * BN_ROW + P * 32 + h * 16);
+            unsigned long long *g = reinterpret_cast<unsigned long long *>(d + (unsigned long long)((k + kk) * 32 + h * 16));
+            H2W_GSTORE64(g, v0.x); H2W_GSTORE64(g + 1, v0.y);
+        }
+    }
+}
 template <bool STAGED> struct BnEmit {
     fr_t *out; uint64_t ninv; fr_t r2;
     char *lds; int lane, cnt;
-    __device__ __forceinline__ void flush() {
-        typedef unsigned long long ull; struct __attribute__((aligned(16))) q16 { ull x, y; };
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
-        const unsigned long long mydst = (unsigned long long)out;
-#pragma unroll 4
-        for (int it = 0; it < 16; it++) {   // per store instruction: 4 permutations x 256 contiguous bytes (8 cells)
-            const int P = it * 4 + (lane >> 4), k = (lane & 15) >> 1, h = lane & 1;
-            const unsigned long long d = __shfl(mydst, P, 64);
-#pragma unroll
-            for (int kk = 0; kk < BN_CH; kk += 8) {
-                const q16 v0 = *reinterpret_cast<const q16 *>(lds + (k + kk) * BN_ROW + P * 32 + h * 16);
-                unsigned long long *g = reinterpret_cast<unsigned long long *>(d + (unsigned long long)((k + kk) * 32 + h * 16));
-                H2W_GSTORE64(g, v0.x); H2W_GSTORE64(g + 1, v0.y);
-            }
-        }
-        out += BN_CH; cnt = 0;
-    }
+    __device__ __forceinline__ void flush() { bn_flush(lds, (unsigned long long)out, lane); out += BN_CH; cnt = 0; }
     __device__ __forceinline__ void put(const fr_t &v) {
         if (STAGED) { *reinterpret_cast<fr_t *>(lds + cnt * BN_ROW + lane * 32) = v; if (++cnt == BN_CH) flush(); }
         else *out++ = v;
     }
     __device__ __forceinline__ void put64(uint64_t v) { fr_t t = fr_from_u64(v); put(t); }
     __device__ __forceinline__ fr_t exp5(const fr_t &x) {
-        const fr_t X = fr_mont_mul(x, r2, ninv);
-        const fr_t x2 = fr_mont_mul(x, X, ninv), X2 = fr_mont_mul(X, X, ninv);
-        const fr_t x4 = fr_mont_mul(x2, X2, ninv), x5 = fr_mont_mul(x4, X, ninv);
+        const fr_t X = mont_nv(x, r2, ninv);
+        const fr_t x2 = mont_nv(x, X, ninv), X2 = mont_nv(X, X, ninv);
+        const fr_t x4 = mont_nv(x2, X2, ninv), x5 = mont_nv(x4, X, ninv);
         put64(0); put(x); put(x); put(x2);
         put64(0); put(x2); put(x2); put(x4);
         put64(0); put(x4); put(x); put(x5);
         return x5;
     }
     __device__ __forceinline__ void ark(fr_t *s, int it) {
-#pragma unroll
         for (int i = 0; i < 4; i++) { const fr_t c = c_bn[0].c[it + i]; put(c); put(s[i]); put(c); put64(1); s[i] = fr_add(s[i], c); put(s[i]); }
     }
     __device__ __forceinline__ fr_t mul_add(const fr_t &c, const fr_t &cm, const fr_t &x, const fr_t &acc) {   // [acc, c, x, c*x+acc]
-        const fr_t v = fr_add(fr_mont_mul(x, cm, ninv), acc);
+        const fr_t v = fr_add(mont_nv(x, cm, ninv), acc);
         put(acc); put(c); put(x); put(v);
         return v;
     }
     __device__ __forceinline__ void mix(fr_t *s, const h2w_fr_t (*mc)[4], const h2w_fr_t (*mm)[4], bool &zero_cached) {
         if (!zero_cached) { put64(0); zero_cached = true; }
         fr_t ns[4];
-#pragma unroll
         for (int i = 0; i < 4; i++) {
             fr_t acc = fr_zero();
-#pragma unroll
             for (int j = 0; j < 4; j++) acc = mul_add(mc[j][i], mm[j][i], s[j], acc);
             ns[i] = acc;
         }
-#pragma unroll
         for (int i = 0; i < 4; i++) s[i] = ns[i];
     }
     __device__ __forceinline__ void permute(fr_t *s, bool zero_cached) {
@@ -281,9 +279,7 @@ template <bool STAGED> struct BnEmit {
                     const fr_t c = c_bn[0].c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r];
                     put(c); put(s[0]); put(c); put64(1); s[0] = fr_add(s[0], c); put(s[0]);
                     fr_t ns0 = fr_zero();
-#pragma unroll
                     for (int j = 0; j < 4; j++) { const int ix = (BN_WIDTH * 2 - 1) * r + j; put(c_bn[0].s[ix]); ns0 = mul_add(c_bn[0].s[ix], c_bn[1].s[ix], s[j], ns0); }
-#pragma unroll
                     for (int kk = 1; kk < 4; kk++) { const int ix = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1; put(c_bn[0].s[ix]); s[kk] = mul_add(c_bn[0].s[ix], c_bn[1].s[ix], s[0], s[kk]); }
                     s[0] = ns0;
                 }
@@ -292,12 +288,10 @@ template <bool STAGED> struct BnEmit {
             for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(c_bn[0].m[i][j]);
             for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(c_bn[0].p[i][j]);
             for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
-#pragma unroll
                 for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
                 ark(s, half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
                 mix(s, c_bn[0].m, c_bn[1].m, zero_cached);
             }
-#pragma unroll
             for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
             if (half == 0) { ark(s, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(s, c_bn[0].p, c_bn[1].p, zero_cached); }
             else mix(s, c_bn[0].m, c_bn[1].m, zero_cached);
@@ -367,7 +361,7 @@ struct h2w_plan {
     uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
-    hipEvent_t evr[EV_RING][4];
+    hipEvent_t evr[EV_RING][5];
     bool fifo_emit = false;   // H2W_FIFO_EMIT=1: serialise the emit phases of successive calls (diagnostic)
     hipEvent_t t_done; bool t_done_valid = false;   // end of the previous call's emit phase (any stream): emit phases run FIFO
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
@@ -463,7 +457,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         H2W_HIP(hipMemcpy(pl->d_ncells, nc.data(), nc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         H2W_HIP(hipMalloc((void **)&pl->d_inv, inv.size() * sizeof(fr_t)));
         H2W_HIP(hipMemcpy(pl->d_inv, inv.data(), inv.size() * sizeof(fr_t), hipMemcpyHostToDevice));
-        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 4; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
+        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
         H2W_HIP(hipEventCreateWithFlags(&pl->t_done, hipEventDisableTiming));
         pl->ev_ready = true;
         return 0;
@@ -482,7 +476,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->ev_ready) (void)hipEventDestroy(p->t_done);
-    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 4; i++) (void)hipEventDestroy(p->evr[r][i]);
+    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
     delete p;
 }
@@ -517,7 +511,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
     A.bn_perm_cells = 4032; A.role_base = 0;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e && e[0] == '1'; } A.dbg_skip_perm = dbg; }
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e ? atoi(e) : 0; } A.dbg_skip_perm = dbg; }
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
@@ -536,6 +530,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         // emit phase starts here: the HBM-bound kernels of successive calls (issued on different streams) run FIFO,
         // so the latency-bound value strands of call k+1 overlap the emit phase of call k instead of all calls phase-locking
         if (p->fifo_emit && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
+        H2W_HIP(hipEventRecord(p->ev[4], stream));   // end of the value strands, start of the BN254 unit emission
         if (g_const_owner != (const void *)p) {   // (re)load the constant-memory tables for this plan, ordered on `stream`
             H2W_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_bn), p->h_bn, sizeof(p->h_bn), 0, hipMemcpyHostToDevice, stream));
             g_const_owner = (const void *)p;
@@ -544,6 +539,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
         if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64 + zblocks)), dim3(64), 0, stream, A);
     }
+    if (p->shape.hash_mode == 0) H2W_HIP(hipEventRecord(p->ev[4], stream));
     H2W_HIP(hipEventRecord(p->ev[1], stream));
     if (p->fifo_emit && p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
     ExpandArgs E;
@@ -573,16 +569,17 @@ int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest
     H2W_HIP(hipGetLastError());
     return 0;
 }
-int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[4]) {   // `back` batches before the last one (ring of 64)
+int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batches before the last one (ring of 64)
     if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing: no such batch"); return -1; }
     hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
     H2W_HIP(hipEventSynchronize(ev[2]));
     H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[3]));   // prologue strands
-    H2W_HIP(hipEventElapsedTime(&ms[1], ev[3], ev[1]));   // query + merkle strands
-    H2W_HIP(hipEventElapsedTime(&ms[2], ev[1], ev[2]));   // expansion kernel
-    H2W_HIP(hipEventElapsedTime(&ms[3], ev[0], ev[2]));   // whole batch
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[3], ev[4]));   // query + Merkle strands
+    H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[1]));   // BN254 permutation-unit emission (0 for GL-Poseidon Merkle)
+    H2W_HIP(hipEventElapsedTime(&ms[3], ev[1], ev[2]));   // expansion kernel
+    H2W_HIP(hipEventElapsedTime(&ms[4], ev[0], ev[2]));   // whole batch
     return 0;
 }
-int h2w_plan_last_timing(h2w_plan *p, float ms[4]) { return h2w_plan_timing(p, 0, ms); }
+int h2w_plan_last_timing(h2w_plan *p, float ms[5]) { return h2w_plan_timing(p, 0, ms); }
 
 }  // extern "C"

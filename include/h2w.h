@@ -152,10 +152,11 @@ int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, ui
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the call's stream:
- * ms[0] = prologue strands, ms[1] = query + Merkle strands, ms[2] = expansion kernel, ms[3] = whole batch.
+ * ms[0] = prologue strands, ms[1] = query + Merkle strands, ms[2] = BN254 permutation-unit emission,
+ * ms[3] = expansion kernel, ms[4] = whole batch.
  * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
-int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[4]);
-int h2w_plan_last_timing(h2w_plan *, float ms[4]);
+int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
+int h2w_plan_last_timing(h2w_plan *, float ms[5]);
 /* Advice cells per proof written by the expansion kernel (the rest are written directly by the value kernels). */
 uint64_t h2w_plan_num_record_cells(const h2w_plan *);
 

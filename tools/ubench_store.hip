@@ -37,6 +37,23 @@ __global__ void kE(q16 *out, uint64_t ncells, uint32_t chunk, int barrier) {
         if (barrier) __syncthreads();
     }
 }
+// F: unit-kernel-like: each wave owns 64 regions (region_cells apart); per step it writes `chunk` B to each region:
+// a store instruction covers (1024/chunk) regions x chunk contiguous bytes
+__global__ void kF(q16 *out, uint64_t ncells, uint32_t region_cells, uint32_t chunk) {
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / 64);
+    const uint32_t lanes_per_region = chunk / 16, regions_per_instr = 64 / lanes_per_region;
+    for (uint64_t w = wave; (w + 1) * 64 * region_cells <= ncells; w += nwaves) {
+        const uint64_t base = w * 64 * region_cells;   // cells
+        for (uint32_t off = 0; off < region_cells * 32; off += chunk) {          // byte offset inside every region
+            for (uint32_t it = 0; it < 64 / regions_per_instr; it++) {
+                const uint64_t region = it * regions_per_instr + lane / lanes_per_region;
+                char *p = (char *)out + (base + region * region_cells) * 32 + off + (lane % lanes_per_region) * 16;
+                q16 v{region, off}; *(q16 *)p = v;
+            }
+        }
+    }
+}
 template <class F> float timeit(F f) { hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); f(); hipDeviceSynchronize(); hipEventRecord(e0); for (int i = 0; i < 3; i++) f(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 3; }
 int main() {
     const uint64_t ncells = 400ull << 20;   // 12.8 GB
@@ -53,6 +70,10 @@ int main() {
     for (uint32_t chunk : {256u, 1024u, 2100u, 8192u}) for (int barrier : {0, 1}) for (int blocks : {2048, 8192}) {
         float e = timeit([&] { hipLaunchKernelGGL(kE, dim3(blocks), dim3(256), 0, 0, out, ncells, chunk, barrier); });
         printf("E chunk %5u cells barrier %d blocks %5d: %.0f GB/s\n", chunk, barrier, blocks, gb / (e * 1e-3));
+    }
+    for (uint32_t chunk : {256u, 512u, 1024u}) for (int blocks : {1345, 4096}) {
+        float f = timeit([&] { hipLaunchKernelGGL(kF, dim3(blocks), dim3(64), 0, 0, out, ncells, 4032u, chunk); });
+        printf("F region 4032 cells, chunk %4u B, %d one-wave blocks: %.0f GB/s\n", chunk, blocks, gb / (f * 1e-3));
     }
     return 0;
 }
