@@ -173,6 +173,15 @@ def main():
     isol = [sum(t[k] for t in iso) / len(iso) for k in range(5)] if iso else overl
     exp_ms = isol[3]
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), when they cover this workload
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg3_bn254_b32.json")))
+        if pj.get("workload") == f"{args.config}/{args.hash}/B{B}/L{args.lookup_bits}":
+            traffic = pj["kernels"]["expand_kernel"]["hbm_bytes"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         total_cells = plan.num_cells * total_proofs * args.steps
         value = total_cells / elapsed
@@ -192,7 +201,7 @@ def main():
             "kernel_ms_isolated": {"prologue": isol[0], "strands": isol[1], "bn254_units": isol[2], "expand": isol[3], "batch": isol[4]},
             "kernel_ms_timed_region": {"prologue": overl[0], "strands": overl[1], "bn254_units": overl[2], "expand": overl[3], "batch": overl[4]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "expand_kernel",
+                         "traffic": traffic, "algorithmic_bytes": exp_cells * 32, "kernel": "expand_kernel",
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS,
                          "note": f"expand_kernel launched alone ({len(iso)} calibration launches after the timed region, library HIP events on the launch stream): 32 B x {exp_cells} cells per launch ({plan.num_record_cells} of {plan.num_cells} cells/proof come from block records; the others are PoseidonBN254 permutation units / direct cells); record+meta reads {B * rec_bytes / 1e6:.1f} MB extra. whole_job_frac = value x 32 B / peak (all kernels, overlapped batches)"},
         }
