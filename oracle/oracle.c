@@ -61,6 +61,7 @@ void orc_ctx_free(octx_t *c) {
     for (int i = 0; i < c->nnames; i++) free(c->names[i]);
     free(c->names); free(c);
 }
+void orc_ctx_reserve(octx_t *c, uint64_t ncells) { if (ncells > c->cap) { c->cap = ncells; c->advice = (ofr_t *)realloc(c->advice, c->cap * sizeof(ofr_t)); if (!c->advice) { fprintf(stderr, "oracle: OOM\n"); abort(); } } }
 uint64_t orc_num_cells(const octx_t *c) { return c->n; } /* util/context_wrapper.rs:24-26 */
 const ofr_t *orc_advice(const octx_t *c) { return c->advice; }
 const char *orc_error(const octx_t *c) { return c->failed ? c->err : ""; }
@@ -249,7 +250,8 @@ static oav_t gate_select_by_indicator(octx_t *c, const oav_t *a, int stride, con
 }
 /* inner_product(a, b) where b are constants; b[0]==1 selects the short form */
 static oav_t gate_inner_product_const(octx_t *c, const qc_t *a, const ofr_t *b, int n) {
-    qc_t *cells = (qc_t *)malloc((size_t)(1 + 3 * n) * sizeof(qc_t)); int *g = (int *)malloc((size_t)(n + 1) * sizeof(int));
+    qc_t cells_s[1 + 3 * 16]; int g_s[17];
+    qc_t *cells = n <= 16 ? cells_s : (qc_t *)malloc((size_t)(1 + 3 * n) * sizeof(qc_t)); int *g = n <= 16 ? g_s : (int *)malloc((size_t)(n + 1) * sizeof(int));
     int k = 0, ng = 0, start = 0; ofr_t sum;
     ofr_t one = fr_from_u64(1);
     if (n > 0 && fr_eq(&b[0], &one)) { cells[k++] = a[0]; sum = a[0].v; start = 1; }
@@ -259,7 +261,8 @@ static oav_t gate_inner_product_const(octx_t *c, const qc_t *a, const ofr_t *b, 
         g[ng++] = k - 1; cells[k++] = a[i]; cells[k++] = Q_C(b[i]); cells[k++] = Q_W(sum);
     }
     assign_region(c, cells, k, g, ng);
-    free(cells); free(g); return ctx_last(c);
+    if (n > 16) { free(cells); free(g); }
+    return ctx_last(c);
 }
 static ofr_t fr_pow2(int k) { ofr_t r = {{0, 0, 0, 0}}; r.l[k >> 6] = 1ULL << (k & 63); return r; }
 static uint64_t fr_bits(const ofr_t *v, int lo, int width) { /* extract `width` (<=64) bits at bit offset lo */
@@ -293,7 +296,8 @@ static void range_check(octx_t *c, oav_t a, int range_bits) {
     oav_t last;
     if (num_limbs == 1) { add_lookup(c, a.cell); last = a; }
     else {
-        qc_t *q = (qc_t *)malloc((size_t)num_limbs * sizeof(qc_t)); ofr_t *b = (ofr_t *)malloc((size_t)num_limbs * sizeof(ofr_t));
+        qc_t q_s[16]; ofr_t b_s[16];
+        qc_t *q = num_limbs <= 16 ? q_s : (qc_t *)malloc((size_t)num_limbs * sizeof(qc_t)); ofr_t *b = num_limbs <= 16 ? b_s : (ofr_t *)malloc((size_t)num_limbs * sizeof(ofr_t));
         for (int i = 0; i < num_limbs; i++) { q[i] = Q_W(fr_from_u64(fr_bits(&a.v, i * L, L))); b[i] = fr_pow2(i * L); }
         int64_t row = (int64_t)c->n;
         oav_t acc = gate_inner_product_const(c, q, b, num_limbs);
@@ -301,7 +305,7 @@ static void range_check(octx_t *c, oav_t a, int range_bits) {
         add_lookup(c, row);
         for (int i = 0; i < num_limbs - 1; i++) add_lookup(c, row + 1 + 3 * i);
         last = ctx_get(c, row + 1 + 3 * (num_limbs - 2));
-        free(q); free(b);
+        if (num_limbs > 16) { free(q); free(b); }
     }
     if (rem == 1) gate_assert_bit(c, last);
     else if (rem > 1) { oav_t chk = gate_mul_q(c, Q_EX(last), Q_C(fr_pow2(L - rem))); add_lookup(c, chk.cell); }
@@ -414,7 +418,13 @@ glw_t orc_gl_reduce(octx_t *c, glw_t a) { /* :346-368 */
     SC("reduce");
     /* 1. hint: quotient = from_noncanonical_biguint(val / ORDER), remainder = from_noncanonical_biguint(val) */
     uint64_t q, r;
-    if (fr_fits_u128(&a.v)) { u128 v = fr_lo128(&a.v); u128 qq = v / GL_P; q = (uint64_t)(qq % GL_P); r = (uint64_t)(v % GL_P); }
+    if (fr_fits_u128(&a.v)) {   /* same values as BigUint val / ORDER and val % ORDER, without a 128-bit divider */
+        u128 v = fr_lo128(&a.v);
+        r = glf_reduce128(v);
+        u128 d = v - r; uint64_t dl = (uint64_t)d; uint64_t qlo = dl + (dl << 32);       /* exact division: p^-1 = 1 + 2^32 mod 2^64 */
+        uint64_t qhi = ((u128)qlo * GL_P != d) ? 1 : 0;
+        q = glf_reduce128(((u128)qhi << 64) | qlo);
+    }
     else { /* generic 256-bit long division by p (never reached on the FRI path) */
         u128 rem = 0; uint64_t ql[4] = {0, 0, 0, 0};
         for (int i = 255; i >= 0; i--) {

@@ -69,6 +69,7 @@ typedef struct octx octx_t;
 octx_t *orc_ctx_new(int lookup_bits, int witness_gen_only, int track_scopes);
 void    orc_ctx_free(octx_t *);
 uint64_t orc_num_cells(const octx_t *);
+void orc_ctx_reserve(octx_t *, uint64_t ncells);   /* capacity hint (avoids realloc copies) */
 const ofr_t *orc_advice(const octx_t *);
 const char *orc_error(const octx_t *);
 /* restated MockProver: returns 0 if all gates / internal equalities / constant equalities / lookups hold.

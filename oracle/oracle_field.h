@@ -104,7 +104,13 @@ static inline ofr_t fr_inv(const ofr_t *a) {
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_NEG_ONE (GL_P - 1)
 #define GL_EPS 0xFFFFFFFFULL
-static inline uint64_t glf_reduce128(u128 x) { return (uint64_t)(x % GL_P); }
+static inline uint64_t glf_reduce128(u128 x) {   /* 2^64 = 2^32 - 1, 2^96 = -1 (mod p) */
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64), hh = hi >> 32, hl = hi & GL_EPS;
+    uint64_t t0 = lo - hh; if (lo < hh) t0 -= GL_EPS;
+    uint64_t t1 = hl * GL_EPS, r = t0 + t1; if (r < t1) r += GL_EPS;
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
 static inline uint64_t glf_add(uint64_t a, uint64_t b) { return glf_reduce128((u128)a + b); }
 static inline uint64_t glf_sub(uint64_t a, uint64_t b) { return glf_reduce128((u128)a + GL_P - b); }
 static inline uint64_t glf_mul(uint64_t a, uint64_t b) { return glf_reduce128((u128)a * b); }

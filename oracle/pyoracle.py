@@ -82,6 +82,7 @@ def lib():
     L.orc_ctx_new.restype = vp
     L.orc_ctx_new.argtypes = [C.c_int, C.c_int, C.c_int]
     L.orc_ctx_free.argtypes = [vp]
+    L.orc_ctx_reserve.argtypes = [vp, C.c_uint64]
     L.orc_num_cells.restype = C.c_uint64
     L.orc_num_cells.argtypes = [vp]
     L.orc_advice.restype = C.POINTER(Fr)
@@ -154,6 +155,9 @@ class Ctx:
             self.close()
         except Exception:
             pass
+
+    def reserve(self, ncells):
+        self.L.orc_ctx_reserve(self.p, ncells)
 
     def num_cells(self):
         return int(self.L.orc_num_cells(self.p))
