@@ -109,6 +109,14 @@ SYMBOLS = {
     "h2w_gl_mul_add": (C.c_int, [_vp, _av, _av, _av, _av]),
     "h2w_gl_div": (C.c_int, [_vp, _av, _av, _av]),
     "h2w_gl_inv": (C.c_int, [_vp, _av, _av]),
+    "h2w_chip_ext_op": (C.c_int, [_vp, C.c_int, _av, _av, _av, _av]),
+    "h2w_chip_gl_exp_from_bits_const_base": (C.c_int, [_vp, C.c_uint64, _av, C.c_size_t, _av]),
+    "h2w_chip_gl_poseidon_permute": (C.c_int, [_vp, C.POINTER(PoseidonConsts), _av, _av]),
+    "h2w_chip_bn_poseidon_permute": (C.c_int, [_vp, C.POINTER(PoseidonConsts), _av, _av]),
+    "h2w_chip_hash_no_pad": (C.c_int, [_vp, C.POINTER(PoseidonConsts), C.c_int, _av, C.c_size_t, _av]),
+    "h2w_chip_two_to_one": (C.c_int, [_vp, C.POINTER(PoseidonConsts), C.c_int, _av, _av, _av]),
+    "h2w_chip_merkle_verify": (C.c_int, [_vp, C.POINTER(PoseidonConsts), C.c_int, _av, C.c_size_t, _av, C.c_size_t, _av, _av, C.c_size_t, _av, C.c_size_t]),
+    "h2w_chip_verify_stark": (C.c_int, [_vp, C.POINTER(Shape), C.POINTER(PoseidonConsts), C.POINTER(C.c_uint64)]),
     "h2w_ctx_advice_device": (C.c_int, [_vp, C.POINTER(_vp)]),
     "h2w_ctx_download": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _fr]),
     "h2w_plan_compile": (_vp, [C.POINTER(Shape), C.POINTER(PoseidonConsts), C.c_int]),

@@ -124,6 +124,21 @@ int h2w_gl_mul_add(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, 
 int h2w_gl_div(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);     /* :371-393 (93); error if b == 0 (:379) */
 int h2w_gl_inv(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                              /* :395-399 (94) */
 
+/* ------------------------------------------------------------------ 2b. the reference's higher chips over the eager boundary
+ * (host side above the C-ABI: csrc/chips.h + csrc/verifier.h instantiated on a backend that only calls the functions above).
+ * Hash wires are 4 assigned values (hash_mode 0: PoseidonHashWire.elements) or 1 (hash_mode 1: PoseidonBN254HashWire.value;
+ * outputs replicate it 4x). */
+int h2w_chip_ext_op(h2w_ctx *, int op, const h2w_assigned_t a[2], const h2w_assigned_t b[2], const h2w_assigned_t c[2], h2w_assigned_t out[2]); /* field/goldilocks/extension.rs: 0 add 1 sub 2 mul 3 square 4 inv 5 div 6 mul_add 7 scalar_mul 8 scalar_div */
+int h2w_chip_gl_exp_from_bits_const_base(h2w_ctx *, uint64_t base, const h2w_assigned_t *bits, size_t n, h2w_assigned_t *out);                 /* base.rs:407-430 */
+int h2w_chip_gl_poseidon_permute(h2w_ctx *, const h2w_poseidon_consts_t *, const h2w_assigned_t in[12], h2w_assigned_t out[12]);             /* hash/poseidon/permutation.rs:270-284 */
+int h2w_chip_bn_poseidon_permute(h2w_ctx *, const h2w_poseidon_consts_t *, const h2w_assigned_t in[4], h2w_assigned_t out[4]);               /* hash/poseidon_bn254/permutation.rs:190-203 */
+int h2w_chip_hash_no_pad(h2w_ctx *, const h2w_poseidon_consts_t *, int hash_mode, const h2w_assigned_t *in, size_t n, h2w_assigned_t out[4]); /* HasherChip::hash_no_pad */
+int h2w_chip_two_to_one(h2w_ctx *, const h2w_poseidon_consts_t *, int hash_mode, const h2w_assigned_t l[4], const h2w_assigned_t r[4], h2w_assigned_t out[4]); /* HasherChip::two_to_one */
+int h2w_chip_merkle_verify(h2w_ctx *, const h2w_poseidon_consts_t *, int hash_mode, const h2w_assigned_t *leaf, size_t n_leaf,
+                           const h2w_assigned_t *index_bits, size_t n_bits, const h2w_assigned_t *cap_index,
+                           const h2w_assigned_t *cap, size_t n_cap, const h2w_assigned_t *siblings, size_t n_sib);                               /* merkle/mod.rs:57-78 */
+int h2w_chip_verify_stark(h2w_ctx *, const h2w_shape_t *, const h2w_poseidon_consts_t *, const uint64_t *proof_words);                         /* stark/mod.rs:483-508 */
+
 /* ------------------------------------------------------------------ advice hand-off (eager contexts) */
 /* Expands all pending records on the GPU; *dev_ptr receives a device pointer to num_cells*32 bytes
  * owned by the context (valid until the next h2w_* call on it). */
