@@ -112,6 +112,7 @@ template <class Sink> struct ValBackend {
         for (int i = 0; i < nbits; i++) { cell64(0); cell64(out[i]); cell64(out[i]); cell64(out[i]); }
     }
     HF Gl bits_to_num(const Bool *bits, int n) {          // inner_product(bits, [1,2,4,..])
+        if (n <= 0) { cell64(0); return 0; }              // inner_product of nothing: the single cell [0] (cap_height 0)
         uint64_t acc = bits[0]; cell64(bits[0]);
         for (int i = 1; i < n; i++) { acc += bits[i] << i; cell64(bits[i]); sink.cell(fr_pow2(i)); cell64(acc); }
         return acc;
