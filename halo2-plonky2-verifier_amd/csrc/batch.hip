@@ -24,12 +24,6 @@ typedef ChallengeBlock<DevB> DevCB;
 typedef ValBackend<CoopSink> CoopB;
 typedef ValBackend<QuadSink> QuadB;   // same wire types as DevB: ChallengeBlock layouts coincide
 
-// PoseidonBN254 constants for the unit kernel, canonical [0] and Montgomery form [1], in CONSTANT address space:
-// wave-uniform reads become scalar loads (lgkmcnt), which — unlike vector loads — do not queue behind the kernel's own
-// outstanding cell stores on vmcnt.  One table per device context; re-uploaded on the stream when a plan with
-// different constants runs (g_const_owner).
-struct BnConsts { h2w_fr_t c[88], s[392], m[4][4], p[4][4]; };
-__constant__ BnConsts c_bn[2];
 static const void *g_const_owner = nullptr;
 
 struct PlanSink {
@@ -43,6 +37,7 @@ struct PlanSink {
     bool coop_load_proof(const ValCfg &) { return false; }
     void bn_native(fr_t *, const h2w_poseidon_consts_t *, const FrParams &) {}
     bool unit_writer() const { return false; }
+    bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     int coop_lanes() { return 1; }
     int coop_lane() { return 0; }
     uint64_t lane_bcast(uint64_t v, int) { return v; }
@@ -524,20 +519,27 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
         hipLaunchKernelGGL(k_merkle_gl_coop, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
     } else {
-        // BN254 Merkle chain strands (4 lanes each), then the query glue (1 lane each)
-        A.role_base = p->d.n_oracles + p->d.n_steps;   // y slot of the glue strands
-        hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + 63) / 64, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(64), 0, stream, A);
-        // emit phase starts here: the HBM-bound kernels of successive calls (issued on different streams) run FIFO,
-        // so the latency-bound value strands of call k+1 overlap the emit phase of call k instead of all calls phase-locking
-        if (p->fifo_emit && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
-        H2W_HIP(hipEventRecord(p->ev[4], stream));   // end of the value strands, start of the BN254 unit emission
-        if (g_const_owner != (const void *)p) {   // (re)load the constant-memory tables for this plan, ordered on `stream`
+        if (g_const_owner != (const void *)p) {   // (re)load the constant-memory BN254 tables for this plan, ordered on `stream`
             H2W_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_bn), p->h_bn, sizeof(p->h_bn), 0, hipMemcpyHostToDevice, stream));
             g_const_owner = (const void *)p;
         }
-        const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
-        const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
-        if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64 + zblocks)), dim3(64), 0, stream, A);
+        static int two_pass = -1;
+        if (two_pass < 0) { const char *e = getenv("H2W_BN_UNITS"); two_pass = e && e[0] == '1'; }
+        if (!two_pass) {
+            // PoseidonBN254 Merkle chain strands (4 lanes each) emit their permutations' cells themselves; extra y slot: query glue
+            A.role_base = p->d.n_oracles + p->d.n_steps;
+            hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + 63) / 64, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(64), 0, stream, A);
+            H2W_HIP(hipEventRecord(p->ev[4], stream));
+        } else {
+            // A/B path (H2W_BN_UNITS=1): one lane per chain stores every permutation's input state as a unit, a second kernel
+            // (one lane per permutation) re-evaluates the units and emits their cells
+            A.role_base = 0;
+            hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+            H2W_HIP(hipEventRecord(p->ev[4], stream));
+            const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
+            const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
+            if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64 + zblocks)), dim3(64), 0, stream, A);
+        }
     }
     if (p->shape.hash_mode == 0) H2W_HIP(hipEventRecord(p->ev[4], stream));
     H2W_HIP(hipEventRecord(p->ev[1], stream));

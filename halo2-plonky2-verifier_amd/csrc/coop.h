@@ -11,6 +11,13 @@
 
 namespace h2w {
 
+// PoseidonBN254 constants for the unit kernel, canonical [0] and Montgomery form [1], in CONSTANT address space:
+// wave-uniform reads become scalar loads (lgkmcnt), which — unlike vector loads — do not queue behind the kernel's own
+// outstanding cell stores on vmcnt.  One table per device context; re-uploaded on the stream when a plan with
+// different constants runs (g_const_owner).
+struct BnConsts { h2w_fr_t c[88], s[392], m[4][4], p[4][4]; };
+__constant__ BnConsts c_bn[2];
+
 constexpr int GLP_RECS_FULL = 12 + 48 + 1 + 12 * 14;           // constant_layer, sbox_layer, mds_layer
 constexpr int GLP_RECS_PARTIAL_ROUND = 4 + 1 + 1 + 11 + 1 + 11; // sbox, +const, d = m00*s0, d chain, zeros, v row
 constexpr int GLP_RECS_PARTIAL = 12 + 1 + 121 + N_PARTIAL_ROUNDS * GLP_RECS_PARTIAL_ROUND;
@@ -65,6 +72,7 @@ struct CoopSink {
     __device__ void bn_perm_end(bool) {}
     __device__ void note_load(uint64_t, int) {}
     __device__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
+    __device__ bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
     __device__ __noinline__ bool coop_load_proof(const ValCfg &cfg) {
         for (uint32_t i = lane; i < cfg.n_load_items; i += 64) {
@@ -235,6 +243,84 @@ struct QuadSink {
         fr_t r;
 #pragma unroll
         for (int i = 0; i < 4; i++) r.l[i] = __shfl_xor(v.l[i], m, 4);
+        return r;
+    }
+    // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself (hash/poseidon_bn254/permutation.rs:48-203):
+    // lane i owns state element i and writes the cells of "its" ops (x^5 of element i, ark i, row i of the mix, term j of the
+    // sparse row, column update k), each a contiguous run of 5-16 cells.  Hybrid arithmetic: canonical state, constants
+    // pre-multiplied by R for const*var products, x^5 in 5 Montgomery products.  No second pass over the permutations.
+    __device__ __noinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc) {
+        const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
+        fr_t *base = out + cell_off;
+        fr_t s = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
+        auto W = [&](fr_t *p, const fr_t &v) { g_store_fr(p, v); };
+        auto W64 = [&](fr_t *p, uint64_t v) { g_store_fr(p, fr_from_u64(v)); };
+        auto exp5 = [&](fr_t *p) {                      // 12 cells at p
+            const fr_t X = fr_mont_mul(s, r2, ninv);
+            const fr_t x2 = fr_mont_mul(s, X, ninv), X2 = fr_mont_mul(X, X, ninv);
+            const fr_t x4 = fr_mont_mul(x2, X2, ninv), x5 = fr_mont_mul(x4, X, ninv);
+            W64(p, 0); W(p + 1, s); W(p + 2, s); W(p + 3, x2);
+            W64(p + 4, 0); W(p + 5, x2); W(p + 6, x2); W(p + 7, x4);
+            W64(p + 8, 0); W(p + 9, x4); W(p + 10, s); W(p + 11, x5);
+            s = x5;
+        };
+        auto add_const = [&](fr_t *p, const fr_t &c) { W(p, c); W(p + 1, s); W(p + 2, c); W64(p + 3, 1); s = fr_add(s, c); W(p + 4, s); };   // [c][s, c, 1, s+c]
+        auto ark = [&](int it) { add_const(base + 5 * l, c_bn[0].c[it + l]); base += 20; };
+        auto mix = [&](int which) {                      // which 0: M, 1: P
+            if (!zc) { if (l == 0) W64(base, 0); base += 1; zc = true; }
+            fr_t acc = fr_zero(); fr_t *p = base + 16 * l;
+            for (int j = 0; j < 4; j++) {
+                const fr_t sj = shfl4(s, j);
+                const fr_t mc = which ? c_bn[0].p[j][l] : c_bn[0].m[j][l], mm = which ? c_bn[1].p[j][l] : c_bn[1].m[j][l];
+                const fr_t nacc = fr_add(fr_mont_mul(sj, mm, ninv), acc);
+                W(p + 4 * j, acc); W(p + 4 * j + 1, mc); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, nacc); acc = nacc;
+            }
+            s = acc; base += 64;
+        };
+        auto consts32 = [&]() {                          // load_constant of M then P (full_rounds prologue)
+            for (int u = 0; u < 8; u++) { const int t = 8 * l + u; W(base + t, t < 16 ? c_bn[0].m[t >> 2][t & 3] : c_bn[0].p[(t - 16) >> 2][t & 3]); }
+            base += 32;
+        };
+        ark(0);
+        for (int half = 0; half < 2; half++) {
+            if (half == 1) {
+                for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                    if (l == 0) { exp5(base); add_const(base + 12, c_bn[0].c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]); }
+                    base += 17;
+                    const fr_t s0 = shfl4(s, 0);
+                    const int ix = (BN_WIDTH * 2 - 1) * r + l;
+                    const fr_t pr = fr_mont_mul(s, c_bn[1].s[ix], ninv);            // S[j] * s_j (lane 0: new s0)
+                    fr_t incl = pr, t = shfl4_up(incl, 1); if (l >= 1) incl = fr_add(incl, t);
+                    t = shfl4_up(incl, 2); if (l >= 2) incl = fr_add(incl, t);
+                    fr_t excl = shfl4_up(incl, 1); if (l == 0) excl = fr_zero();
+                    { fr_t *p = base + 5 * l; W(p, c_bn[0].s[ix]); W(p + 1, excl); W(p + 2, c_bn[0].s[ix]); W(p + 3, s); W(p + 4, incl); }
+                    base += 20;
+                    const fr_t ns0 = shfl4(incl, 3);
+                    if (l > 0) {
+                        const int iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + l - 1; fr_t *p = base + 5 * (l - 1);
+                        const fr_t nv = fr_add(fr_mont_mul(s0, c_bn[1].s[iy], ninv), s);
+                        W(p, c_bn[0].s[iy]); W(p + 1, s); W(p + 2, c_bn[0].s[iy]); W(p + 3, s0); W(p + 4, nv); s = nv;
+                    } else s = ns0;
+                    base += 15;
+                }
+            }
+            consts32();
+            for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
+                exp5(base + 12 * l); base += 48;
+                ark(half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
+                mix(0);
+            }
+            exp5(base + 12 * l); base += 48;
+            if (half == 0) { ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(1); } else mix(0);
+        }
+        for (int j = 0; j < 4; j++) st[j] = shfl4(s, j);
+        cell_off = (uint64_t)(base - out);
+        return true;
+    }
+    static __device__ __forceinline__ fr_t shfl4_up(const fr_t &v, int d) {
+        fr_t r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.l[i] = __shfl_up(v.l[i], d, 4);
         return r;
     }
     __device__ __noinline__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) {

@@ -187,6 +187,7 @@ template <class Sink> struct ValBackend {
     // ---------------------------------------------------------------- BN254 permutation units
     HF bool bn_perm_unit(Fr *st, const h2w_poseidon_consts_t *) {
         if (!cfg.split_bn) return false;
+        if (sink.bn_emit_inline(st, cfg, zero_cached)) return true;      // the strand's own lanes emit the permutation's cells (QuadSink)
         fr_t *u = cfg.units + 4 * unit_idx; unit_idx++;
         if (sink.unit_writer()) for (int i = 0; i < 4; i++) g_store_fr(u + i, st[i]);
         sink.bn_native(st, cfg.consts_mont, cfg.P);
@@ -240,6 +241,7 @@ struct DevSink {
     HF bool coop_load_proof(const ValCfg &) { return false; }
     HF void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
     HF bool unit_writer() const { return true; }
+    HF bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     HF int coop_lanes() { return 1; }
     HF int coop_lane() { return 0; }
     HF uint64_t lane_bcast(uint64_t v, int) { return v; }
