@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight, each on its own HIP stream with its own advice/workspace buffers (0 = auto)")
     ap.add_argument("--calib", type=int, default=5, help="isolated single-stream launches after the timed region for the roofline numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
+    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -88,8 +90,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.share_gpu0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -118,8 +122,12 @@ def main():
         for i in range(total_proofs):
             pr = O.synth_proof(osh, 0xF1B00000 + i)
             host[i * words:(i + 1) * words] = torch.frombuffer(bytearray(bytes(pr)), dtype=torch.int64)
-    all_proofs = host.to(dev)
-    D.broadcast_proofs(all_proofs, src=0)           # the only collective (RCCL over xGMI): ingest rank -> all ranks
+    if args.backend == "gloo":                      # rehearsal: broadcast on the host, then upload
+        D.broadcast_proofs(host, src=0)
+        all_proofs = host.to(dev)
+    else:
+        all_proofs = host.to(dev)
+        D.broadcast_proofs(all_proofs, src=0)       # the only collective (RCCL over xGMI): ingest rank -> all ranks
     lo, hi = D.shard_range(total_proofs, world, rank)
     assert hi - lo == B
     my_proofs = all_proofs[lo * words:hi * words]
@@ -153,7 +161,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
+    elapsed = D.max_over_ranks(elapsed, torch.device("cpu") if args.backend == "gloo" else dev)
     for i in range(S):
         status = plan.status(wss[i].data_ptr(), B, streams[i].cuda_stream)
         assert status == [0] * B, f"device status {status}"
