@@ -82,6 +82,9 @@ SYMBOLS = {
     "h2w_ctx_free": (None, [_vp]),
     "h2w_num_cells": (C.c_uint64, [_vp]),
     "h2w_ctx_error": (C.c_int, [_vp]),
+    "h2w_push_context": (C.c_int, [_vp, C.c_char_p]),
+    "h2w_pop_context": (C.c_int, [_vp]),
+    "h2w_context_dump": (C.c_size_t, [_vp, C.c_char_p, C.c_size_t]),
     "h2w_load_constant": (C.c_int, [_vp, _fr, _av]),
     "h2w_load_zero": (C.c_int, [_vp, _av]),
     "h2w_load_constants": (C.c_int, [_vp, _fr, C.c_size_t, _av]),

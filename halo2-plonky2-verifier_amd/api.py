@@ -37,6 +37,19 @@ class Context:
     def num_cells(self):  # ContextWrapper::num_cells
         return int(self.L.h2w_num_cells(self.p))
 
+    def push_context(self, name):  # ContextWrapper::push_context (what #[count] emits on entry)
+        _ck(self.L.h2w_push_context(self.p, name.encode()), "h2w_push_context")
+
+    def pop_context(self):
+        _ck(self.L.h2w_pop_context(self.p), "h2w_pop_context")
+
+    def cell_counts(self):
+        """{"all;verify_proof;...": inclusive cells} — the data behind the reference's profile/*.svg flamegraphs."""
+        n = self.L.h2w_context_dump(self.p, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.L.h2w_context_dump(self.p, buf, n + 1)
+        return {line.rsplit(" ", 1)[0]: int(line.rsplit(" ", 1)[1]) for line in buf.value.decode().splitlines()}
+
     def advice_bytes(self, first=0, count=None):
         """Expands the pending records on the GPU and returns canonical-LE cells as bytes."""
         n = self.num_cells() if count is None else count

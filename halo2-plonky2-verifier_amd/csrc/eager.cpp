@@ -32,6 +32,9 @@ struct h2w_ctx {
     bool zero_set = false; uint64_t zero_off = 0;
     int err = 0;
     std::vector<fr_t> inv_pos, inv_neg;
+    // ContextTree (util/context_tree.rs:11-123): scoped cell counters
+    struct Node { int parent; std::string name; uint64_t cells; std::vector<int> children; };
+    std::vector<Node> nodes{Node{-1, "all", 0, {}}}; int cur = 0; std::vector<uint64_t> enter;
     // device side
     void *d_out = nullptr, *d_meta = nullptr, *d_recs = nullptr, *d_pool = nullptr;
     DeviceTables dt;
@@ -264,6 +267,32 @@ int h2w_limbs_to_num(h2w_ctx *c, const h2w_assigned_t *limbs, size_t n, size_t l
 int h2w_check_less_than_safe(h2w_ctx *c, const h2w_assigned_t *a, uint64_t b) { if (!check(c, "h2w_check_less_than_safe")) return -1; t_check_less_than_safe(c, *a, b); return 0; }
 int h2w_range_check(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits) { if (!check(c, "h2w_range_check")) return -1; t_range_check(c, *a, range_bits); return 0; }
 int h2w_constrain_equal(h2w_ctx *c, const h2w_assigned_t *, const h2w_assigned_t *) { return check(c, "h2w_constrain_equal") ? 0 : -1; }
+
+// ---------------------------------------------------------------- ContextWrapper::{push_context, pop_context} (util/context_wrapper.rs:28-34)
+int h2w_push_context(h2w_ctx *c, const char *name) {
+    if (!check(c, "h2w_push_context") || !name) return -1;
+    int ch = -1;
+    for (int k : c->nodes[c->cur].children) if (c->nodes[k].name == name) { ch = k; break; }
+    if (ch < 0) { ch = (int)c->nodes.size(); c->nodes.push_back(h2w_ctx::Node{c->cur, name, 0, {}}); c->nodes[c->cur].children.push_back(ch); }
+    c->enter.push_back(c->ncells); c->cur = ch; return 0;
+}
+int h2w_pop_context(h2w_ctx *c) {
+    if (!check(c, "h2w_pop_context")) return -1;
+    if (c->enter.empty()) return fail(c, "h2w_pop_context: no open context");
+    c->nodes[c->cur].cells += c->ncells - c->enter.back(); c->enter.pop_back(); c->cur = c->nodes[c->cur].parent; return 0;
+}
+// collapsed-stack dump "a;b;c <inclusive cells>\n" (util/context_tree.rs:132-152 writes own counts; inclusive is what the SVG frames show)
+size_t h2w_context_dump(const h2w_ctx *c, char *buf, size_t cap) {
+    if (!c) return 0;
+    std::string out;
+    std::vector<std::string> path(c->nodes.size());
+    for (size_t i = 0; i < c->nodes.size(); i++) {
+        path[i] = c->nodes[i].parent < 0 ? c->nodes[i].name : path[(size_t)c->nodes[i].parent] + ";" + c->nodes[i].name;
+        out += path[i] + " " + std::to_string(i == 0 ? c->ncells : c->nodes[i].cells) + "\n";
+    }
+    if (buf && cap) { size_t n = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), n); buf[n] = 0; }
+    return out.size();
+}
 
 // ---------------------------------------------------------------- fused Goldilocks level (field/goldilocks/base.rs)
 static inline bool gl_canon(const fr_t &v) { return fits64(v) && v.l[0] < GL_P; }

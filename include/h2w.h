@@ -88,6 +88,11 @@ h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id);   /*
 void     h2w_ctx_free(h2w_ctx *);
 uint64_t h2w_num_cells(const h2w_ctx *);                                        /* util/context_wrapper.rs:24-26 */
 int      h2w_ctx_error(const h2w_ctx *);                                        /* sticky error flag of the context */
+/* scoped cell counters: what the reference's #[count] proc-macro (macro/src/lib.rs:9-61) drives through
+ * ContextWrapper::push_context / pop_context (util/context_wrapper.rs:28-34, util/context_tree.rs) */
+int      h2w_push_context(h2w_ctx *, const char *name);
+int      h2w_pop_context(h2w_ctx *);
+size_t   h2w_context_dump(const h2w_ctx *, char *buf, size_t cap);              /* "a;b;c <inclusive cells>\n" lines; returns bytes needed */
 /* field/native.rs:28-46 */
 int h2w_load_constant(h2w_ctx *, const h2w_fr_t *c, h2w_assigned_t *out);
 int h2w_load_zero(h2w_ctx *, h2w_assigned_t *out);

@@ -59,6 +59,23 @@ def test_eager_cell_counts_without_gpu(h2w_api):
     ctx.close()
 
 
+def test_scoped_cell_counters(h2w_api):
+    """ContextWrapper push_context / pop_context: the #[count] tree of GoldilocksChip::mul (65 cells)."""
+    ctx = h2w_api.Context(21); nat = h2w_api.NativeChip(ctx); gl = h2w_api.GoldilocksChip(nat)
+    a, b = gl.load_constant(3), gl.load_constant(5)
+    ctx.push_context("mul")
+    ctx.push_context("mul_no_reduce"); p = nat.mul(a, b); ctx.pop_context()
+    ctx.push_context("reduce"); gl.reduce(p); ctx.pop_context()
+    ctx.pop_context()
+    ctx.push_context("mul"); gl.mul(a, b); ctx.pop_context()
+    cc = ctx.cell_counts()
+    assert cc["all"] == ctx.num_cells() == 2 + 65 + 65
+    assert cc["all;mul"] == 130 and cc["all;mul;mul_no_reduce"] == 4 and cc["all;mul;reduce"] == 61
+    with pytest.raises(h2w_api.H2WError):
+        ctx.pop_context()
+    ctx.close()
+
+
 def test_no_cpu_fallback(h2w_api, h2w):
     """Without a HIP device the product refuses to produce cells (it must never route through a CPU path)."""
     if h2w.lib().h2w_device_count() > 0:
