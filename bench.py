@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight, each on its own HIP stream with its own advice/workspace buffers (0 = auto)")
     ap.add_argument("--calib", type=int, default=5, help="isolated single-stream launches after the timed region for the roofline numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cu-split", type=int, default=0, help="experiment: CU-masked streams, value strands on the first N CUs, expansion on the rest")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -140,12 +141,26 @@ def main():
     advices = [torch.empty(B * cell_bytes, dtype=torch.uint8, device=dev) for _ in range(S)]
     wss = [torch.empty(plan.workspace_bytes(B), dtype=torch.uint8, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    emit_streams = [None] * S
+    if args.cu_split > 0:      # hipExtStreamCreateWithCUMask: value strands on CUs [0, N), streaming kernel on [N, 256)
+        hip = C.CDLL("libamdhip64.so")
+        def masked(lo, hi):
+            words = (C.c_uint32 * 8)()
+            for cu in range(lo, hi):
+                words[cu // 32] |= 1 << (cu % 32)
+            st = C.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words)
+            assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
+            return torch.cuda.ExternalStream(st.value, device=dev)
+        streams = [masked(0, args.cu_split) for _ in range(S)]
+        emit_streams = [masked(args.cu_split, 256) for _ in range(S)]
     torch.cuda.synchronize()
     counter = [0]
 
     def step():
         i = counter[0] % S; counter[0] += 1
-        plan.run(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
+        plan.run(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream,
+                 emit_streams[i].cuda_stream if emit_streams[i] is not None else None)
 
     for _ in range(args.warmup):
         step()

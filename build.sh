@@ -2,7 +2,7 @@
 # Builds libh2w.so (HIP, gfx950) in-tree.  hipcc cross-compiles without a GPU.
 set -e
 cd "$(dirname "$0")/halo2-plonky2-verifier_amd/csrc"
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-value -x hip"
+FLAGS="$H2W_EXTRA -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-value -x hip"
 mkdir -p ../build
 pids=()
 for f in expand.hip eager.cpp batch.hip abi_backend.cpp; do

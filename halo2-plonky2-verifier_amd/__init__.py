@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libh2w.so")
+LIB_PATH = os.environ.get("H2W_LIB") or os.path.join(_HERE, "libh2w.so")   # H2W_LIB: A/B builds of the same library
 
 
 class Fr(C.Structure):
@@ -129,6 +129,7 @@ SYMBOLS = {
     "h2w_plan_num_records": (C.c_uint64, [_vp]),
     "h2w_plan_workspace_bytes": (C.c_uint64, [_vp, C.c_uint64]),
     "h2w_fri_witness_batch": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "h2w_fri_witness_batch2": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "h2w_plan_status": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint32), _vp]),
     "h2w_advice_digest": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "h2w_plan_last_timing": (C.c_int, [_vp, C.POINTER(C.c_float)]),

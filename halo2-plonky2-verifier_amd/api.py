@@ -190,8 +190,11 @@ class Plan:
     def workspace_bytes(self, n):
         return int(self.L.h2w_plan_workspace_bytes(self.p, n))
 
-    def run(self, proofs_ptr, n, advice_ptr, workspace_ptr, stream=0):
-        _ck(self.L.h2w_fri_witness_batch(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream), "h2w_fri_witness_batch")
+    def run(self, proofs_ptr, n, advice_ptr, workspace_ptr, stream=0, emit_stream=None):
+        if emit_stream is None:
+            _ck(self.L.h2w_fri_witness_batch(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream), "h2w_fri_witness_batch")
+        else:
+            _ck(self.L.h2w_fri_witness_batch2(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, emit_stream), "h2w_fri_witness_batch2")
 
     def status(self, workspace_ptr, n, stream=0):
         st = (C.c_uint32 * n)()

@@ -80,7 +80,12 @@ __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     return c;
 }
 
-__global__ __launch_bounds__(64) void k_prologue(BatchArgs A) {
+// Register budget of the strand kernels (the attribute propagates to their callees): H2W_QUAD_WAVES wavefronts per SIMD.
+#ifndef H2W_QUAD_WAVES
+#define H2W_QUAD_WAVES 1
+#endif
+#define H2W_WAVES __attribute__((amdgpu_waves_per_eu(H2W_QUAD_WAVES, H2W_QUAD_WAVES)))
+__global__ __launch_bounds__(64) H2W_WAVES void k_prologue(BatchArgs A) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.nproofs) return;
     DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells;
@@ -135,15 +140,18 @@ __device__ void glue_lane(const BatchArgs &A, int idx) {   // FriChip::verify_qu
     V.query_round(q, A.cbs[p]);
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
-__global__ __launch_bounds__(64) void k_merkle_bn_quad(BatchArgs A) {
+__global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_merkle_bn_quad(BatchArgs A) {
     __builtin_amdgcn_s_setprio(3);
     const int nq = A.shape.num_queries, total = A.nproofs * nq;
     if ((int)blockIdx.y == A.role_base) {               // last y slot: the query glue strands, one lane each
-        const int gi = blockIdx.x * 64 + threadIdx.x;
-        if (gi < total) glue_lane(A, gi);
+        const int gi = blockIdx.x * QUAD_BLOCK + threadIdx.x;
+        if (gi < total && !(A.dbg_skip_perm & 8)) glue_lane(A, gi);
         return;
     }
-    int idx = (blockIdx.x * 64 + threadIdx.x) >> 2;
+    stage_bn_consts(threadIdx.x, QUAD_BLOCK);
+    if (A.dbg_skip_perm & 16) return;
+    if ((int)((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63)) >> 2) >= total) return;      // a wavefront past the last strand
+    int idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
     if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes): keeps shuffles in-quad valid
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(64) void k_merkle_bn_quad(BatchArgs A) {
 }
 
 // blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
-__global__ __launch_bounds__(64) void k_strands(BatchArgs A) {
+__global__ __launch_bounds__(64) H2W_WAVES void k_strands(BatchArgs A) {
     __builtin_amdgcn_s_setprio(3);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = A.shape.num_queries;
@@ -213,7 +221,6 @@ constexpr int BN_CH = 8;
 constexpr int BN_ROW = 64 * 32 + 32;   // bytes per staged cell row
 // One out-of-line copy of the Montgomery product (arguments and result in VGPRs, by value): the unit kernel has ~25 call
 // sites and must stay inside the 64 KB instruction cache (fully inlined it was ~400 KB and ran instruction-fetch bound).
-__device__ __attribute__((noinline)) fr_t mont_nv(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }
 __device__ __attribute__((noinline)) void bn_flush(const char *lds, unsigned long long mydst, int lane) {
     typedef unsigned long long ull; struct __attribute__((aligned(16))) q16 { ull x, y; };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -239,9 +246,9 @@ template <bool STAGED> struct BnEmit {
     }
     __device__ __forceinline__ void put64(uint64_t v) { fr_t t = fr_from_u64(v); put(t); }
     __device__ __forceinline__ fr_t exp5(const fr_t &x) {
-        const fr_t X = mont_nv(x, r2, ninv);
-        const fr_t x2 = mont_nv(x, X, ninv), X2 = mont_nv(X, X, ninv);
-        const fr_t x4 = mont_nv(x2, X2, ninv), x5 = mont_nv(x4, X, ninv);
+        const fr_t X = mont_call(x, r2, ninv);
+        const fr_t x2 = mont_call(x, X, ninv), X2 = mont_call(X, X, ninv);
+        const fr_t x4 = mont_call(x2, X2, ninv), x5 = mont_call(x4, X, ninv);
         put64(0); put(x); put(x); put(x2);
         put64(0); put(x2); put(x2); put(x4);
         put64(0); put(x4); put(x); put(x5);
@@ -251,7 +258,7 @@ template <bool STAGED> struct BnEmit {
         for (int i = 0; i < 4; i++) { const fr_t c = c_bn[0].c[it + i]; put(c); put(s[i]); put(c); put64(1); s[i] = fr_add(s[i], c); put(s[i]); }
     }
     __device__ __forceinline__ fr_t mul_add(const fr_t &c, const fr_t &cm, const fr_t &x, const fr_t &acc) {   // [acc, c, x, c*x+acc]
-        const fr_t v = fr_add(mont_nv(x, cm, ninv), acc);
+        const fr_t v = fr_add(mont_call(x, cm, ninv), acc);
         put(acc); put(c); put(x); put(v);
         return v;
     }
@@ -491,13 +498,17 @@ uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
     if (!p) return 0;
     size_t a, b, c, d2, t; ws_layout(p, n_proofs, a, b, c, d2, t); return t;
 }
+int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_);
 int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
+    return h2w_fri_witness_batch2(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_);
+}
+int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_) {
     if (!p) { set_error("h2w_fri_witness_batch: null plan"); return -1; }
     if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
     if (n_proofs * (uint64_t)p->shape.num_queries > 0x7fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
-    hipStream_t stream = (hipStream_t)stream_;
+    hipStream_t stream = (hipStream_t)stream_, estream = (hipStream_t)emit_stream_;
     size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
     char *ws = (char *)workspace_dev;
     BatchArgs A;
@@ -511,7 +522,9 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
     H2W_HIP(hipEventRecord(p->ev[0], stream));
-    hipLaunchKernelGGL(k_prologue_coop, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
+    static int dbg_skip = -1;      // timing experiments only (H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion) — results are then garbage
+    if (dbg_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); dbg_skip = e ? atoi(e) : 0; }
+    if (!(dbg_skip & 1)) hipLaunchKernelGGL(k_prologue_coop, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
     H2W_HIP(hipEventRecord(p->ev[3], stream));
     const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
     // roles: 0 = query glue, then one role per merkle strand kind (initial oracles, fold steps)
@@ -528,7 +541,7 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
         if (!two_pass) {
             // PoseidonBN254 Merkle chain strands (4 lanes each) emit their permutations' cells themselves; extra y slot: query glue
             A.role_base = p->d.n_oracles + p->d.n_steps;
-            hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + 63) / 64, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(64), 0, stream, A);
+            if (!(dbg_skip & 2)) hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(QUAD_BLOCK), 0, stream, A);
             H2W_HIP(hipEventRecord(p->ev[4], stream));
         } else {
             // A/B path (H2W_BN_UNITS=1): one lane per chain stores every permutation's input state as a unit, a second kernel
@@ -548,9 +561,11 @@ int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_pr
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
     p->dt.fill(E); E.rb = p->tt.rb;
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
-    launch_expand(E, n_proofs, gx, stream);
-    H2W_HIP(hipEventRecord(p->ev[2], stream));
-    H2W_HIP(hipEventRecord(p->t_done, stream)); p->t_done_valid = true;
+    if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, p->ev[1], 0));    // value strands done -> expansion on the emit stream
+    if (!(dbg_skip & 4)) launch_expand(E, n_proofs, gx, estream);
+    H2W_HIP(hipEventRecord(p->ev[2], estream));
+    if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, p->ev[2], 0));    // the caller's stream completes when the advice is complete
+    H2W_HIP(hipEventRecord(p->t_done, estream)); p->t_done_valid = true;
     p->ev_recorded = true;
     H2W_HIP(hipGetLastError());
     return 0;

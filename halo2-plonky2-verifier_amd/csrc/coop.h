@@ -209,6 +209,47 @@ struct CoopSink {
 // strand's direct cells) and split the width-4 PoseidonBN254 state between them for the value-domain permutation:
 // full rounds 4-way parallel (x^5, then each lane one output row of the mix), partial rounds: lane 0 does the S-box,
 // all four lanes one product of the sparse row, lanes 1-3 their column update (5 instead of 14 dependent products).
+// Montgomery product as a real call, for code that is not store-bound.  NOT for the quad emitter: every AMDGPU function entry starts
+// with s_waitcnt vmcnt(0), i.e. waits for all cell stores in flight.
+__device__ __attribute__((noinline)) fr_t mont_call(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }
+
+// per-quad LDS staging regions of the BN254 quad emitter (QuadSink::stage / flush): 16 quads x QST cells = 16 KB per wavefront,
+// small enough for two wavefronts per SIMD (one computes while the other drains its stores)
+#ifndef H2W_QST
+#define H2W_QST 64
+#endif
+#ifndef H2W_QUAD_BLOCK
+#define H2W_QUAD_BLOCK 64
+#endif
+#ifndef H2W_BN_LDS
+#define H2W_BN_LDS 0
+#endif
+constexpr int QST = H2W_QST;
+static_assert(QST >= 64, "the emitter stages a whole 64-cell mix layer");
+constexpr int QUAD_BLOCK = H2W_QUAD_BLOCK;                   // threads per block of k_merkle_bn_quad: 4 wavefronts share one LDS copy of the constants
+struct __attribute__((aligned(16))) sq16_t { unsigned long long x, y; };
+__shared__ sq16_t s_quad_stage[(QUAD_BLOCK / 4) * QST * 2];
+// The PoseidonBN254 tables (c_bn[0] canonical for the cells, c_bn[1] pre-multiplied by R for the products) in LDS.  The emitter
+// indexes them by lane; from constant/global memory that is a vector load, and on gfx9-family parts loads and stores share
+// vmcnt in order, so waiting for a constant means waiting for every cell store issued before it (microseconds of HBM write
+// latency per flush).  LDS reads count on lgkmcnt and leave the stores in flight.
+enum { BK_C = 0, BK_S = 88, BK_M = 88 + 392, BK_P = 88 + 392 + 16, BK_N = 88 + 392 + 32 };
+#if H2W_BN_LDS
+__shared__ sq16_t s_bn_k[2 * BK_N * 2];
+__device__ __forceinline__ void stage_bn_consts(int tid, int nthreads) {
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c_bn);
+    for (int i = tid; i < 2 * BK_N * 2; i += nthreads) s_bn_k[i] = sq16_t{src[2 * i], src[2 * i + 1]};
+    __syncthreads();
+}
+__device__ __forceinline__ fr_t bnk(int which, int idx) {
+    const sq16_t a = s_bn_k[(which * BK_N + idx) * 2], b = s_bn_k[(which * BK_N + idx) * 2 + 1];
+    fr_t r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = b.x; r.l[3] = b.y; return r;
+}
+#else
+__device__ __forceinline__ void stage_bn_consts(int, int) {}
+__device__ __forceinline__ fr_t bnk(int which, int idx) { return c_bn[which].c[idx]; }   // c, s, m, p are contiguous: one flat index (address space stays constant memory)
+#endif
+
 struct QuadSink {
     static constexpr bool kCoop = false;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4;
@@ -245,76 +286,127 @@ struct QuadSink {
         for (int i = 0; i < 4; i++) r.l[i] = __shfl_xor(v.l[i], m, 4);
         return r;
     }
+    // Staged cell store.  A lane that writes a whole 32-byte cell alone issues two 16-byte stores into its own cache line; 64
+    // such lines per store instruction hold the write path to ~3 TB/s device-wide (tools/ubench_store2.hip), while a quad writing
+    // 64 contiguous bytes per instruction streams at the HBM ceiling.  So the owner lanes put their cells into the quad's LDS
+    // region (s_quad_stage, QST cells) and the quad flushes the region, which is contiguous in the advice stream, with all four
+    // lanes writing adjacent 16-byte pieces.  `off` is the cell offset inside the region, negative when this lane has no cell.
+    static __device__ __forceinline__ void stage(int off, const fr_t &v) {
+        if (off >= 0) { sq16_t *q = reinterpret_cast<sq16_t *>(s_quad_stage) + ((threadIdx.x >> 2) * QST + off) * 2; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]}; }
+    }
+    // (static, lane index by value: a member read after wave_sync's memory clobber is a FLAT load from the sink object, and a flat
+    // load waits for vmcnt(0), i.e. for every cell store still in flight)
+    static __device__ __forceinline__ void flush(fr_t *&base, int &n, const int l4) {
+#ifdef H2W_ABL_NOFLUSH2
+        if (n != 12345) { base += n; n = 0; return; }
+#endif
+        wave_sync();
+        const sq16_t *src = reinterpret_cast<const sq16_t *>(s_quad_stage) + (threadIdx.x >> 2) * QST * 2;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(base);
+        const int np = 2 * n;                                        // 16-byte pieces; lane k of the quad takes pieces k, k+4, ...
+#pragma unroll
+        for (int u = 0; u < QST / 2; u += 4) {                       // 4 LDS reads in flight, then their 4 stores
+            sq16_t t[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) t[v] = src[pc]; }
+#pragma unroll
+#ifdef H2W_ABL_NOFLUSH
+            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np && t[v].x == 0x123456789abcull) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
+#else
+            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
+#endif
+            if ((u + 4) * 4 >= np) break;
+        }
+        wave_sync();
+        base += n; n = 0;
+    }
     // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself (hash/poseidon_bn254/permutation.rs:48-203):
-    // lane i owns state element i and writes the cells of "its" ops (x^5 of element i, ark i, row i of the mix, term j of the
+    // lane i owns state element i and the cells of "its" ops (x^5 of element i, ark i, row i of the mix, term j of the
     // sparse row, column update k), each a contiguous run of 5-16 cells.  Hybrid arithmetic: canonical state, constants
     // pre-multiplied by R for const*var products, x^5 in 5 Montgomery products.  No second pass over the permutations.
-    __device__ __noinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc) {
+    __device__ __noinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
+        bool zc = zc_ref;                      // by value: a reference would be re-read with a flat load (vmcnt(0)) at every mix
         const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
-        fr_t *base = out + cell_off;
+        fr_t *base = out + cell_off;          // advice position of the staging region's first cell
+        int so = 0;                           // cells staged (quad-uniform)
         fr_t s = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
-        auto W = [&](fr_t *p, const fr_t &v) { g_store_fr(p, v); };
-        auto W64 = [&](fr_t *p, uint64_t v) { g_store_fr(p, fr_from_u64(v)); };
-        auto exp5 = [&](fr_t *p) {                      // 12 cells at p
+#ifdef H2W_ABL_NOSTORE
+        auto W = [&](int off, const fr_t &v) { if (cfg.P.ninv == 12345) stage(off < 0 ? -1 : so + off, v); };
+#else
+        auto W = [&](int off, const fr_t &v) { stage(off < 0 ? -1 : so + off, v); };
+#endif
+        auto W64 = [&](int off, uint64_t v) { W(off, fr_from_u64(v)); };
+        auto need = [&](int n) { if (so + n > QST) flush(base, so, l); };
+        // x^5: 12 cells at region offset p (p < 0: this lane has no S-box here and keeps its s)
+        auto exp5 = [&](int p) {
             const fr_t X = fr_mont_mul(s, r2, ninv);
             const fr_t x2 = fr_mont_mul(s, X, ninv), X2 = fr_mont_mul(X, X, ninv);
             const fr_t x4 = fr_mont_mul(x2, X2, ninv), x5 = fr_mont_mul(x4, X, ninv);
-            W64(p, 0); W(p + 1, s); W(p + 2, s); W(p + 3, x2);
-            W64(p + 4, 0); W(p + 5, x2); W(p + 6, x2); W(p + 7, x4);
-            W64(p + 8, 0); W(p + 9, x4); W(p + 10, s); W(p + 11, x5);
-            s = x5;
+            const int q = p < 0 ? -64 : p;                            // q + i stays negative
+            W64(q, 0); W(q + 1, s); W(q + 2, s); W(q + 3, x2);
+            W64(q + 4, 0); W(q + 5, x2); W(q + 6, x2); W(q + 7, x4);
+            W64(q + 8, 0); W(q + 9, x4); W(q + 10, s); W(q + 11, x5);
+            if (p >= 0) s = x5;
         };
-        auto add_const = [&](fr_t *p, const fr_t &c) { W(p, c); W(p + 1, s); W(p + 2, c); W64(p + 3, 1); s = fr_add(s, c); W(p + 4, s); };   // [c][s, c, 1, s+c]
-        auto ark = [&](int it) { add_const(base + 5 * l, c_bn[0].c[it + l]); base += 20; };
+        auto add_const = [&](int p, const fr_t &c) {                  // [c][s, c, 1, s+c]
+            const int q = p < 0 ? -64 : p; const fr_t ns = fr_add(s, c);
+            W(q, c); W(q + 1, s); W(q + 2, c); W64(q + 3, 1); W(q + 4, ns);
+            if (p >= 0) s = ns;
+        };
+        auto ark = [&](int it) { need(20); add_const(5 * l, bnk(0, BK_C + it + l)); so += 20; };
         auto mix = [&](int which) {                      // which 0: M, 1: P
-            if (!zc) { if (l == 0) W64(base, 0); base += 1; zc = true; }
-            fr_t acc = fr_zero(); fr_t *p = base + 16 * l;
+            if (!zc) { need(1); W64(l == 0 ? 0 : -64, 0); so += 1; zc = true; }
+            need(64);
+            fr_t acc = fr_zero(); const int p = 16 * l;
             for (int j = 0; j < 4; j++) {
                 const fr_t sj = shfl4(s, j);
-                const fr_t mc = which ? c_bn[0].p[j][l] : c_bn[0].m[j][l], mm = which ? c_bn[1].p[j][l] : c_bn[1].m[j][l];
-                const fr_t nacc = fr_add(fr_mont_mul(sj, mm, ninv), acc);
-                W(p + 4 * j, acc); W(p + 4 * j + 1, mc); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, nacc); acc = nacc;
+                const fr_t nacc = fr_add(fr_mont_mul(sj, bnk(1, (which ? BK_P : BK_M) + 4 * j + l), ninv), acc);
+                W(p + 4 * j, acc); W(p + 4 * j + 1, bnk(0, (which ? BK_P : BK_M) + 4 * j + l)); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, nacc); acc = nacc;
             }
-            s = acc; base += 64;
+            s = acc; so += 64;
         };
         auto consts32 = [&]() {                          // load_constant of M then P (full_rounds prologue)
-            for (int u = 0; u < 8; u++) { const int t = 8 * l + u; W(base + t, t < 16 ? c_bn[0].m[t >> 2][t & 3] : c_bn[0].p[(t - 16) >> 2][t & 3]); }
-            base += 32;
+            need(32);
+            for (int u = 0; u < 8; u++) { const int t = 8 * l + u; W(t, bnk(0, BK_M + t)); }
+            so += 32;
         };
         ark(0);
         for (int half = 0; half < 2; half++) {
             if (half == 1) {
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-                    if (l == 0) { exp5(base); add_const(base + 12, c_bn[0].c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]); }
-                    base += 17;
+                    need(52);
+                    exp5(l == 0 ? 0 : -64); add_const(l == 0 ? 12 : -64, bnk(0, BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r));
+                    so += 17;
                     const fr_t s0 = shfl4(s, 0);
                     const int ix = (BN_WIDTH * 2 - 1) * r + l;
-                    const fr_t pr = fr_mont_mul(s, c_bn[1].s[ix], ninv);            // S[j] * s_j (lane 0: new s0)
+                    const fr_t pr = fr_mont_mul(s, bnk(1, BK_S + ix), ninv);            // S[j] * s_j (lane 0: new s0)
                     fr_t incl = pr, t = shfl4_up(incl, 1); if (l >= 1) incl = fr_add(incl, t);
                     t = shfl4_up(incl, 2); if (l >= 2) incl = fr_add(incl, t);
                     fr_t excl = shfl4_up(incl, 1); if (l == 0) excl = fr_zero();
-                    { fr_t *p = base + 5 * l; W(p, c_bn[0].s[ix]); W(p + 1, excl); W(p + 2, c_bn[0].s[ix]); W(p + 3, s); W(p + 4, incl); }
-                    base += 20;
+                    { const int p = 5 * l; W(p, bnk(0, BK_S + ix)); W(p + 1, excl); W(p + 2, bnk(0, BK_S + ix)); W(p + 3, s); W(p + 4, incl); }
+                    so += 20;
                     const fr_t ns0 = shfl4(incl, 3);
-                    if (l > 0) {
-                        const int iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + l - 1; fr_t *p = base + 5 * (l - 1);
-                        const fr_t nv = fr_add(fr_mont_mul(s0, c_bn[1].s[iy], ninv), s);
-                        W(p, c_bn[0].s[iy]); W(p + 1, s); W(p + 2, c_bn[0].s[iy]); W(p + 3, s0); W(p + 4, nv); s = nv;
-                    } else s = ns0;
-                    base += 15;
+                    {
+                        const int lm = l > 0 ? l - 1 : 0, iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + lm, p = l > 0 ? 5 * lm : -64;
+                        const fr_t nv = fr_add(fr_mont_mul(s0, bnk(1, BK_S + iy), ninv), s);
+                        W(p, bnk(0, BK_S + iy)); W(p + 1, s); W(p + 2, bnk(0, BK_S + iy)); W(p + 3, s0); W(p + 4, nv);
+                        s = l > 0 ? nv : ns0;
+                    }
+                    so += 15;
                 }
             }
             consts32();
             for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
-                exp5(base + 12 * l); base += 48;
+                need(48); exp5(12 * l); so += 48;
                 ark(half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
                 mix(0);
             }
-            exp5(base + 12 * l); base += 48;
+            need(48); exp5(12 * l); so += 48;
             if (half == 0) { ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(1); } else mix(0);
         }
+        flush(base, so, l);
         for (int j = 0; j < 4; j++) st[j] = shfl4(s, j);
-        cell_off = (uint64_t)(base - out);
+        cell_off = (uint64_t)(base - out); zc_ref = zc;
         return true;
     }
     static __device__ __forceinline__ fr_t shfl4_up(const fr_t &v, int d) {

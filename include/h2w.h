@@ -167,6 +167,10 @@ uint64_t  h2w_plan_workspace_bytes(const h2w_plan *, uint64_t n_proofs);
  * stream: hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
 int h2w_fri_witness_batch(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs,
                           void *advice_dev, void *workspace_dev, void *stream);
+/* Same, with the HBM-bound expansion kernel issued on `emit_stream` (ordered after the value strands by an event; `stream`
+ * waits for it).  Lets a caller give the latency-bound value strands and the streaming kernel differently CU-masked streams. */
+int h2w_fri_witness_batch2(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs,
+                           void *advice_dev, void *workspace_dev, void *stream, void *emit_stream);
 /* Per-proof device status words (0 = ok; non-zero = reference would have panicked, e.g. inverse of zero) */
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */

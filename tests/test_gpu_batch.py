@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1):
+def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False):
     import torch
     ko, kh = consts
     sh = h2w.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc)
@@ -23,7 +23,11 @@ def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, w
     advice = torch.zeros(n * plan.num_cells * 32, dtype=torch.uint8, device="cuda")
     ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), stream)
+    if split_streams:      # h2w_fri_witness_batch2: expansion kernel on its own stream, ordered by events
+        emit = torch.cuda.Stream()
+        plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), stream, emit.cuda_stream)
+    else:
+        plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), stream)
     torch.cuda.synchronize()
     assert plan.status(ws.data_ptr(), n, stream) == [0] * n
     got = advice.cpu().numpy().tobytes()
@@ -59,6 +63,11 @@ def test_other_lookup_bits(h2w, h2w_api, oracle, consts, lookup_bits):
 def test_config1_full(h2w, h2w_api, oracle, consts, mode):
     """BASELINE.json configs[0]: 2^10 rows, 4 queries."""
     run_batch(h2w, h2w_api, oracle, consts, (10, 4, 1, mode), [0xF1B00001, 0xF1B00011])
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_separate_emit_stream(h2w, h2w_api, oracle, consts, mode):
+    run_batch(h2w, h2w_api, oracle, consts, (8, 3, 1, mode), [21, 22, 23], split_streams=True)
 
 
 def test_config3_bn254_full(h2w, h2w_api, oracle, consts):
