@@ -1173,3 +1173,6 @@ uint64_t orc_glf_primitive_root_of_unity(int bits) { return glf_primitive_root_o
 void orc_fr_mul(const ofr_t *a, const ofr_t *b, ofr_t *out) { fr_init(); *out = fr_mul(a, b); }
 void orc_fr_inv(const ofr_t *a, ofr_t *out) { fr_init(); *out = fr_inv(a); }
 void orc_fr_modulus(ofr_t *out) { *out = FR_MOD; }
+
+/* ===================================================================== native FRI prover (valid synthetic proofs) */
+#include "prover.inc"

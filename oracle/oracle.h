@@ -10,7 +10,9 @@
  * halo2-lib `community-edition`, plonky2/starky, succinctx, all unpinned: verifier/Cargo.toml:14-20)
  * and its tests hold no literal vectors.  What IS pinned: the exact per-call-stack advice-cell counts of
  * verifier/profile/{gl,bn254}.svg (tests/golden/svg_frames_*.json), which this oracle reproduces
- * frame by frame, plus mathematical identities and a restated MockProver (constraint checker).
+ * frame by frame, plus mathematical identities, a restated MockProver (constraint checker), and self-consistency on VALID
+ * FRI instances: prover.inc (a native prover following plonky2's prover conventions) produces proofs on which the restated
+ * gadget satisfies every constraint including the chip-level asserts (tests/test_oracle_valid_proof.py).
  *
  * Every function cites the reference file:line it follows.
  */
@@ -83,6 +85,14 @@ size_t orc_scope_dump(const octx_t *, char *buf, size_t cap);
 void orc_synth_consts(oconsts_t *out, uint64_t seed);
 size_t orc_proof_words(const oshape_t *);                      /* number of u64 words in the flat proof */
 void orc_synth_proof(const oshape_t *, uint64_t seed, uint64_t *words);
+
+/* a VALID FRI instance of the shape (native value-domain prover following plonky2's prover conventions, prover.inc);
+ * on it the restated MockProver must report semantic_failed == 0.  Small shapes only (lde_bits <= 20). */
+int orc_prove_fri(const oshape_t *, const oconsts_t *, uint64_t seed, uint64_t *words);
+/* native (no-cell) twins of the hash gadgets, for cross-checks */
+void orc_nv_gl_permute(const oconsts_t *, uint64_t st[12]);
+void orc_nv_bn_permute(const oconsts_t *, ofr_t st[4]);
+void orc_nv_hash_or_noop(const oconsts_t *, int hash_mode, const uint64_t *in, int n, uint64_t out[4]);
 
 /* --- the path: load_proof_with_pis + StarkChip::verify_proof (stark/mod.rs:483-508) --- */
 int orc_verify_stark(octx_t *, const oshape_t *, const oconsts_t *, const uint64_t *proof_words);

@@ -11,7 +11,7 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h", "oracle_field.h")]
+    src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h", "oracle_field.h", "prover.inc")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
@@ -97,6 +97,11 @@ def lib():
     L.orc_proof_words.restype = C.c_size_t
     L.orc_proof_words.argtypes = [C.POINTER(Shape)]
     L.orc_synth_proof.argtypes = [C.POINTER(Shape), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_prove_fri.restype = C.c_int
+    L.orc_prove_fri.argtypes = [C.POINTER(Shape), C.POINTER(Consts), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_nv_gl_permute.argtypes = [C.POINTER(Consts), C.POINTER(C.c_uint64)]
+    L.orc_nv_bn_permute.argtypes = [C.POINTER(Consts), C.POINTER(Fr)]
+    L.orc_nv_hash_or_noop.argtypes = [C.POINTER(Consts), C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
     L.orc_verify_stark.restype = C.c_int
     L.orc_verify_stark.argtypes = [vp, C.POINTER(Shape), C.POINTER(Consts), C.POINTER(C.c_uint64)]
     frp = C.POINTER(Fr)
@@ -195,6 +200,16 @@ def synth_proof(shape, seed):
     n = lib().orc_proof_words(C.byref(shape))
     buf = (C.c_uint64 * n)()
     lib().orc_synth_proof(C.byref(shape), seed, buf)
+    return buf
+
+
+def prove_fri(shape, consts, seed):
+    """A valid FRI instance of the shape (oracle/prover.inc), flat proof words."""
+    n = lib().orc_proof_words(C.byref(shape))
+    buf = (C.c_uint64 * n)()
+    rc = lib().orc_prove_fri(C.byref(shape), C.byref(consts), seed, buf)
+    if rc != 0:
+        raise RuntimeError("orc_prove_fri: unsupported shape")
     return buf
 
 

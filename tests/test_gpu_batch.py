@@ -8,14 +8,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False):
+def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False, valid=False, cap_height=4):
     import torch
     ko, kh = consts
-    sh = h2w.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc)
-    osh = oracle.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc)
+    sh = h2w.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc, cap_height=cap_height)
+    osh = oracle.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc, cap_height=cap_height)
     plan = h2w_api.Plan(sh, kh)
     n = len(seeds)
-    proofs = [oracle.synth_proof(osh, s) for s in seeds]
+    proofs = [oracle.prove_fri(osh, ko, s) if valid else oracle.synth_proof(osh, s) for s in seeds]   # valid: oracle/prover.inc
     host = torch.empty(n * plan.proof_words, dtype=torch.int64)
     for i, p in enumerate(proofs):
         host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
@@ -70,6 +70,15 @@ def test_separate_emit_stream(h2w, h2w_api, oracle, consts, mode):
     run_batch(h2w, h2w_api, oracle, consts, (8, 3, 1, mode), [21, 22, 23], split_streams=True)
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+def test_valid_fri_proofs(h2w, h2w_api, oracle, consts, mode):
+    """Same byte-for-byte parity on VALID FRI instances (every value then sits on the accepting path: Merkle roots match,
+    fold steps agree, PoW response has its leading zeros) — the oracle's MockProver is all-green on these inputs
+    (tests/test_oracle_valid_proof.py)."""
+    run_batch(h2w, h2w_api, oracle, consts, (6, 3, 1, mode), [31, 32], valid=True, cap_height=2)
+    run_batch(h2w, h2w_api, oracle, consts, (9, 2, 1, mode), [33], valid=True, cap_height=2)     # one fold step
+
+
 def test_config3_bn254_full(h2w, h2w_api, oracle, consts):
     """BASELINE.json configs[2]: 2^20 rows, 28 queries, cap_height 4, PoseidonBN254 Merkle — 28.58 M cells, every byte."""
     run_batch(h2w, h2w_api, oracle, consts, (20, 28, 1, 1), [0xF1B00003])
@@ -88,13 +97,13 @@ def _custom(h2w, oracle, **kw):
     return sh, osh
 
 
-def run_custom(h2w, h2w_api, oracle, consts, seeds, **kw):
+def run_custom(h2w, h2w_api, oracle, consts, seeds, valid=False, **kw):
     import torch
     ko, kh = consts
     sh, osh = _custom(h2w, oracle, **kw)
     plan = h2w_api.Plan(sh, kh)
     n = len(seeds)
-    proofs = [oracle.synth_proof(osh, s) for s in seeds]
+    proofs = [oracle.prove_fri(osh, ko, s) if valid else oracle.synth_proof(osh, s) for s in seeds]   # valid: oracle/prover.inc
     host = torch.empty(n * plan.proof_words, dtype=torch.int64)
     for i, p in enumerate(proofs):
         host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
@@ -127,6 +136,9 @@ def test_shape_edge_cases(h2w, h2w_api, oracle, consts, mode):
         assert status == [0, 0], (kw, status)
         for rc, err, n, same in outs:
             assert rc == 0 and n == nc and same, (kw, rc, err, n, nc, same)
+    # and one of them on a valid instance (two fold steps of arity 4)
+    status, outs, nc = run_custom(h2w, h2w_api, oracle, consts, [13], valid=True, mode=mode, **cases[2])
+    assert status == [0] and all(rc == 0 and n == nc and same for rc, err, n, same in outs)
 
 
 def test_device_status_where_reference_panics(h2w, h2w_api, oracle, consts):
