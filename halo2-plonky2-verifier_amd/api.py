@@ -201,6 +201,43 @@ class Plan:
         _ck(self.L.h2w_plan_status(self.p, workspace_ptr, n, st, stream), "h2w_plan_status")
         return list(st)
 
+    # ---- keygen-side metadata and column layout
+    def selectors(self):
+        """Context::selector of the shape's cell stream as a bytes bitmap (bit i of byte i // 8 = cell i)."""
+        buf = (C.c_uint8 * ((self.num_cells + 7) // 8))()
+        _ck(self.L.h2w_plan_selectors(self.p, buf), "h2w_plan_selectors")
+        return bytes(buf)
+
+    def lookup_cells(self):
+        """Cells registered for the range lookup, in registration order."""
+        n = int(self.L.h2w_plan_num_lookups(self.p))
+        buf = (C.c_uint64 * max(n, 1))()
+        _ck(self.L.h2w_plan_lookup_cells(self.p, buf), "h2w_plan_lookup_cells")
+        return list(buf[:n])
+
+    def break_points(self, k, unusable_rows=9):
+        sel = self.selectors()
+        n = C.c_uint64()
+        sb = (C.c_uint8 * len(sel)).from_buffer_copy(sel)
+        _ck(self.L.h2w_break_points(sb, self.num_cells, k, unusable_rows, None, 0, C.byref(n)), "h2w_break_points")
+        out = (C.c_uint64 * max(n.value, 1))()
+        _ck(self.L.h2w_break_points(sb, self.num_cells, k, unusable_rows, out, n.value, C.byref(n)), "h2w_break_points")
+        return list(out[:n.value])
+
+    def layout_columns(self, advice_ptr, n, break_points, k, columns_ptr, stream=0, proof_stride=None):
+        bp = (C.c_uint64 * max(len(break_points), 1))(*break_points)
+        _ck(self.L.h2w_layout_columns(advice_ptr, self.num_cells, self.num_cells if proof_stride is None else proof_stride, n, bp, len(break_points), k, columns_ptr, stream), "h2w_layout_columns")
+
+    def num_lookup_columns(self, k, unusable_rows=9):
+        n = C.c_uint64()
+        _ck(self.L.h2w_layout_lookup_columns(self.p, None, 0, 0, k, unusable_rows, None, C.byref(n), None), "h2w_layout_lookup_columns")
+        return int(n.value)
+
+    def layout_lookup_columns(self, advice_ptr, n, k, out_ptr, unusable_rows=9, stream=0, proof_stride=None):
+        nc = C.c_uint64()
+        _ck(self.L.h2w_layout_lookup_columns(self.p, advice_ptr, self.num_cells if proof_stride is None else proof_stride, n, k, unusable_rows, out_ptr, C.byref(nc), stream), "h2w_layout_lookup_columns")
+        return int(nc.value)
+
     def timing(self, back=0):
         """(prologue ms, strands ms, BN254-unit ms, expansion-kernel ms, total ms) of the batch call `back` calls before
         the last, from HIP events recorded on the call's stream."""

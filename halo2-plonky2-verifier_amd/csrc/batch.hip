@@ -45,8 +45,20 @@ struct PlanSink {
     void end_lane_cells(uint64_t) {}
     void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
     void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
-    void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta->push_back(meta_pack((uint32_t)t, cell_off)); nrec++; cell_off += (uint64_t)tt->ncells(t); }
-    void cell(const fr_t &) { cell_off++; }
+    // keygen metadata pass (h2w_plan_metadata): one bit per cell, set from the template slot flags / the backend's G()/LK() markers
+    std::vector<uint8_t> *sel_bits = nullptr, *lk_bits = nullptr; uint8_t pend = 0;
+    void mark(uint64_t cell, uint8_t f) {
+        if (f & CF_GATE) { if (sel_bits->size() <= cell / 8) sel_bits->resize(cell / 8 + 4096, 0); (*sel_bits)[cell / 8] |= (uint8_t)(1u << (cell & 7)); }
+        if (f & CF_LOOKUP) { if (lk_bits->size() <= cell / 8) lk_bits->resize(cell / 8 + 4096, 0); (*lk_bits)[cell / 8] |= (uint8_t)(1u << (cell & 7)); }
+    }
+    void gate() { pend |= CF_GATE; }
+    void lookup() { pend |= CF_LOOKUP; }
+    void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) {
+        if (meta) meta->push_back(meta_pack((uint32_t)t, cell_off));
+        if (sel_bits) { const tmpl_info_t &ti = tt->info[t]; for (int i = 0; i < ti.ncells; i++) { const uint8_t f = tt->slot_flags[ti.slot_base + i]; if (f) mark(cell_off + i, f); } }
+        nrec++; cell_off += (uint64_t)tt->ncells(t);
+    }
+    void cell(const fr_t &) { if (sel_bits && pend) mark(cell_off, pend); pend = 0; cell_off++; }
     void skip(uint64_t, uint64_t) {}
     void merkle_begin(int, int, bool zc, uint64_t) { mk_rec0 = nrec; mk_cell0 = cell_off; mk_zc = zc; mk_unit0 = nunit; }
     void merkle_end(int q, int kind, bool zc) {
@@ -360,6 +372,8 @@ struct h2w_plan {
     uint64_t nrec = 0, ncells = 0, rec_cells = 0;
     LoadItem *d_items = nullptr; uint32_t n_items = 0; uint64_t load_nrec = 0, load_ncell = 0;
     BnConsts h_bn[2];
+    h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
+    bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr;
     uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
@@ -383,7 +397,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         set_error("h2w_plan_compile: unsupported shape"); return nullptr;
     }
     h2w_plan *pl = new h2w_plan(s.lookup_bits);
-    pl->shape = s; pl->device = device_id; pl->P = fr_params_init();
+    pl->shape = s; pl->device = device_id; pl->P = fr_params_init(); pl->h_consts = *consts;
     { const char *e = getenv("H2W_FIFO_EMIT"); pl->fifo_emit = e && e[0] == '1'; }
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
     if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
@@ -477,6 +491,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
+    if (p->d_lookup_cells) (void)hipFree(p->d_lookup_cells);
     if (p->ev_ready) (void)hipEventDestroy(p->t_done);
     if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
@@ -567,6 +582,122 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
     if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, p->ev[2], 0));    // the caller's stream completes when the advice is complete
     H2W_HIP(hipEventRecord(p->t_done, estream)); p->t_done_valid = true;
     p->ev_recorded = true;
+    H2W_HIP(hipGetLastError());
+    return 0;
+}
+// ---- keygen-side metadata of the cell stream: static per shape, computed by a second host replay
+int h2w_plan_metadata(h2w_plan *pl) {
+    if (!pl) { set_error("h2w_plan_metadata: null plan"); return -1; }
+    if (pl->meta_ready) return 0;
+    if (pl->shape.lookup_bits >= 48) { set_error("h2w_plan_metadata: lookup_bits >= 48 makes a single-limb range check look up its SOURCE cell; not tracked"); return -1; }
+    std::vector<fr_t> inv(2 * INV_TAB, fr_zero());
+    for (int k2 = 1; k2 < INV_TAB; k2++) { inv[k2] = fr_inv(fr_from_u64((uint64_t)k2), pl->P); inv[INV_TAB + k2] = fr_neg(inv[k2]); }
+    std::vector<uint64_t> zero_proof(pl->pl.total, 0), unit_cell; std::vector<LoadItem> items; StrandTable st; memset(&st, 0, sizeof(st));
+    pl->sel_bits.assign((size_t)(pl->ncells + 7) / 8, 0); pl->lk_bits.assign((size_t)(pl->ncells + 7) / 8, 0);
+    PlanSink sink; sink.meta = nullptr; sink.tt = &pl->tt; sink.st = &st; sink.unit_cell = &unit_cell; sink.items = &items;
+    sink.sel_bits = &pl->sel_bits; sink.lk_bits = &pl->lk_bits;
+    ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = pl->shape.hash_mode; cfg.L = pl->shape.lookup_bits; cfg.P = pl->P;
+    cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.units = nullptr; cfg.consts_mont = nullptr; cfg.bn_perm_cells = 0; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
+    ValBackend<PlanSink> be(sink, cfg, false);
+    Verifier<ValBackend<PlanSink>> V(be, pl->shape, &pl->h_consts);
+    ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
+    V.run_all(*cb);
+    delete cb;
+    if (sink.cell_off != pl->ncells) { set_error("h2w_plan_metadata: internal: replay length mismatch"); return -1; }
+    pl->sel_bits.resize((size_t)(pl->ncells + 7) / 8); pl->lk_bits.resize((size_t)(pl->ncells + 7) / 8);
+    pl->n_gates = pl->n_lookups = 0;
+    for (uint8_t b : pl->sel_bits) pl->n_gates += (uint64_t)__builtin_popcount(b);
+    for (uint8_t b : pl->lk_bits) pl->n_lookups += (uint64_t)__builtin_popcount(b);
+    pl->meta_ready = true;
+    return 0;
+}
+uint64_t h2w_plan_num_gates(h2w_plan *p) { return p && h2w_plan_metadata(p) == 0 ? p->n_gates : 0; }
+uint64_t h2w_plan_num_lookups(h2w_plan *p) { return p && h2w_plan_metadata(p) == 0 ? p->n_lookups : 0; }
+int h2w_plan_selectors(h2w_plan *p, uint8_t *bitmap) {
+    if (!p || !bitmap) { set_error("h2w_plan_selectors: null argument"); return -1; }
+    if (h2w_plan_metadata(p) != 0) return -1;
+    memcpy(bitmap, p->sel_bits.data(), p->sel_bits.size()); return 0;
+}
+int h2w_plan_lookup_cells(h2w_plan *p, uint64_t *cells) {
+    if (!p || !cells) { set_error("h2w_plan_lookup_cells: null argument"); return -1; }
+    if (h2w_plan_metadata(p) != 0) return -1;
+    uint64_t k2 = 0;
+    for (uint64_t i = 0; i < p->ncells; i++) if (p->lk_bits[i / 8] >> (i & 7) & 1) cells[k2++] = i;     // registration order = stream order (RangeChip::range_check)
+    return 0;
+}
+// FlexGate break points (halo2-base assign_with_constraints, ROTATIONS = 4 [R]): walk the stream down a column of
+// max_rows = 2^k - unusable_rows; break when a gate would not fit or the column is full; the breaking cell is assigned twice
+// (last row of the old column, row 0 of the new one).
+int h2w_break_points(const uint8_t *selectors, uint64_t n_cells, int k, int unusable_rows, uint64_t *out, uint64_t cap, uint64_t *n_out) {
+    if (!selectors || !n_out || k < 3 || k > 40 || unusable_rows < 0 || ((uint64_t)1 << k) <= (uint64_t)unusable_rows + 4) { set_error("h2w_break_points: bad argument"); return -1; }
+    const uint64_t max_rows = ((uint64_t)1 << k) - (uint64_t)unusable_rows; uint64_t row = 0, n = 0;
+    for (uint64_t i = 0; i < n_cells; i++) {
+        const bool q = selectors[i / 8] >> (i & 7) & 1;
+        if ((q && row + 4 > max_rows) || row >= max_rows - 1) { if (out && n < cap) out[n] = row; n++; row = 0; }
+        row++;
+    }
+    *n_out = n;
+    if (out && n > cap) { set_error("h2w_break_points: output too small"); return -1; }
+    return 0;
+}
+// advice -> FlexGate columns on the device: columns[p][c][r], c < n_bp + 1, r < 2^k (unassigned rows zero), 32-byte cells
+__global__ void k_layout_columns(const ulonglong2 *advice, uint64_t proof_stride, const uint64_t *starts, const uint64_t *lens, uint32_t ncols, uint32_t k, ulonglong2 *out) {
+    const uint64_t rows2 = (uint64_t)2 << k;                      // 16-byte halves per column
+    const uint32_t p = blockIdx.z, c = blockIdx.y;
+    const uint64_t start = starts[c], len2 = lens[c] * 2;
+    const ulonglong2 *src = advice + ((uint64_t)p * proof_stride + start) * 2;
+    ulonglong2 *dst = out + ((uint64_t)p * ncols + c) * rows2;
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < rows2; h += (uint64_t)gridDim.x * blockDim.x)
+        dst[h] = h < len2 ? src[h] : make_ulonglong2(0, 0);
+}
+int h2w_layout_columns(const void *advice_dev, uint64_t n_cells, uint64_t proof_stride_cells, uint64_t n_proofs, const uint64_t *break_points, uint64_t n_bp, int k, void *columns_dev, void *stream_) {
+    if (!advice_dev || !columns_dev || (!break_points && n_bp) || k < 3 || k > 34) { set_error("h2w_layout_columns: bad argument"); return -1; }
+    if (n_proofs == 0) return 0;
+    const uint64_t ncols = n_bp + 1; std::vector<uint64_t> h(2 * ncols); uint64_t start = 0;
+    for (uint64_t c = 0; c < ncols; c++) {      // column c holds cells [start, start + len); consecutive columns share their boundary cell
+        const uint64_t len = c < n_bp ? break_points[c] + 1 : n_cells - start;
+        if (start + len > n_cells || len > ((uint64_t)1 << k)) { set_error("h2w_layout_columns: break points do not fit the stream"); return -1; }
+        h[c] = start; h[ncols + c] = len; start += len - (c < n_bp ? 1 : 0);
+    }
+    if (ncols > 65535 || n_proofs > 65535) { set_error("h2w_layout_columns: too many columns / proofs per call"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_; uint64_t *d = nullptr;
+    H2W_HIP(hipMallocAsync((void **)&d, h.size() * sizeof(uint64_t), stream));
+    H2W_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    H2W_HIP(hipStreamSynchronize(stream));      // h is a local
+    const unsigned gx = (unsigned)std::min<uint64_t>((((uint64_t)2 << k) + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_layout_columns, dim3(gx, (unsigned)ncols, (unsigned)n_proofs), dim3(256), 0, stream, (const ulonglong2 *)advice_dev, proof_stride_cells, d, d + ncols, (uint32_t)ncols, (uint32_t)k, (ulonglong2 *)columns_dev);
+    H2W_HIP(hipFreeAsync(d, stream));
+    H2W_HIP(hipGetLastError());
+    return 0;
+}
+// lookup advice: the looked-up cells, in registration order, down columns of max_rows rows [R]; out[p][c][r], r < 2^k
+__global__ void k_layout_lookup(const ulonglong2 *advice, uint64_t proof_stride, const uint32_t *cells, uint64_t n_lookups, uint64_t max_rows, uint32_t ncols, uint32_t k, ulonglong2 *out) {
+    const uint64_t rows = (uint64_t)1 << k, total2 = (uint64_t)ncols * rows * 2; const uint32_t p = blockIdx.y;
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < total2; h += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t cellpos = h >> 1, c = cellpos / rows, r = cellpos % rows, j = c * max_rows + r;
+        ulonglong2 v = make_ulonglong2(0, 0);
+        if (r < max_rows && j < n_lookups) v = advice[((uint64_t)p * proof_stride + cells[j]) * 2 + (h & 1)];
+        out[(uint64_t)p * total2 + h] = v;
+    }
+}
+int h2w_layout_lookup_columns(h2w_plan *p, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs, int k, int unusable_rows, void *out_dev, uint64_t *n_cols_out, void *stream_) {
+    if (!p || k < 3 || k > 34 || unusable_rows < 0) { set_error("h2w_layout_lookup_columns: bad argument"); return -1; }
+    if (h2w_plan_metadata(p) != 0) return -1;
+    const uint64_t max_rows = ((uint64_t)1 << k) - (uint64_t)unusable_rows, ncols = (p->n_lookups + max_rows - 1) / max_rows;
+    if (n_cols_out) *n_cols_out = ncols;
+    if (!out_dev) return 0;                    // size query
+    if (!advice_dev) { set_error("h2w_layout_lookup_columns: null advice"); return -1; }
+    if (p->device < 0) { set_error("h2w_layout_lookup_columns: no HIP device"); return -1; }
+    if (p->ncells >> 32) { set_error("h2w_layout_lookup_columns: stream longer than 2^32 cells"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p->d_lookup_cells && p->n_lookups) {
+        std::vector<uint32_t> h((size_t)p->n_lookups); uint64_t k2 = 0;
+        for (uint64_t i = 0; i < p->ncells; i++) if (p->lk_bits[i / 8] >> (i & 7) & 1) h[k2++] = (uint32_t)i;
+        H2W_HIP(hipMalloc((void **)&p->d_lookup_cells, h.size() * sizeof(uint32_t)));
+        H2W_HIP(hipMemcpy(p->d_lookup_cells, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (n_proofs == 0 || ncols == 0) return 0;
+    hipLaunchKernelGGL(k_layout_lookup, dim3(4096, (unsigned)n_proofs), dim3(256), 0, stream, (const ulonglong2 *)advice_dev, proof_stride_cells, p->d_lookup_cells, p->n_lookups, max_rows, (uint32_t)ncols, (uint32_t)k, (ulonglong2 *)out_dev);
     H2W_HIP(hipGetLastError());
     return 0;
 }

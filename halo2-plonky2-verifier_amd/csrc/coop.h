@@ -57,6 +57,8 @@ struct CoopSink {
     }
     bool lane_mode = false, lane_on = false;     // lane_mode: every enabled lane writes cells at its OWN offset (coop_decompose_hashes)
     __device__ __forceinline__ void cell(const fr_t &v) { if (lane_mode ? lane_on : lane == 0) g_store_fr(out + cell_off, v); cell_off++; }
+    __device__ __forceinline__ void gate() {}
+    __device__ __forceinline__ void lookup() {}
     __device__ bool unit_writer() const { return lane == 0; }
     __device__ int coop_lanes() { return 64; }
     __device__ int coop_lane() { return lane; }
@@ -258,6 +260,8 @@ struct QuadSink {
         nrec++; cell_off += ncells[t];
     }
     __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) g_store_fr(out + cell_off, v); cell_off++; }
+    __device__ __forceinline__ void gate() {}
+    __device__ __forceinline__ void lookup() {}
     __device__ bool unit_writer() const { return l4 == 0; }
     __device__ int coop_lanes() { return 1; }
     __device__ int coop_lane() { return 0; }

@@ -61,9 +61,16 @@ HD uint32_t meta_tmpl(uint64_t m) { return (uint32_t)(m >> 56); }
 HD uint64_t meta_off(uint64_t m) { return m & 0x00FFFFFFFFFFFFFFULL; }
 
 // Host-side template table for a given lookup_bits.
+// per-cell keygen flags (host only): a vertical gate starts at this cell (halo2-base selector,
+// SURVEY App. A) / the cell is registered for the range lookup (RangeChip::range_check limbs)
+enum { CF_GATE = 1, CF_LOOKUP = 2 };
+
 struct TemplateTable {
     int L = 21, rb = 84, nlimb = 4;
     std::vector<uint32_t> slots;
+    std::vector<uint8_t> slot_flags;   // parallel to `slots`
+    std::vector<uint8_t> fl;           // flags of the template under construction (cell index -> CF_*)
+    void flag(const std::vector<uint32_t> &s, int back, uint8_t f) { const size_t i = s.size() - 1 - (size_t)back; if (fl.size() <= i) fl.resize(i + 1, 0); fl[i] |= f; }
     std::vector<tmpl_info_t> info;
     std::vector<fr_t> consts;
     std::map<int, int> rc_ids;  // range_check(bits) -> template id
@@ -77,44 +84,45 @@ struct TemplateTable {
     // range_check(Z, bits) cells: inner product of limbs (n>1) + last-limb fix-up
     void emit_rc(std::vector<uint32_t> &s, int src, int bits) {
         int n = (bits + L - 1) / L, rem = bits % L;
-        if (n > 1) {
-            s.push_back(slot_field(src, 0, L));
+        if (n > 1) {                                       // inner_product(limbs, 2^(jL)): gates at cells 0, 3, 6, ...; every limb looked up
+            s.push_back(slot_field(src, 0, L)); flag(s, 0, CF_GATE | CF_LOOKUP);
             for (int j = 1; j < n; j++) {
-                s.push_back(slot_field(src, j * L, L));
+                s.push_back(slot_field(src, j * L, L)); flag(s, 0, CF_LOOKUP);
                 s.push_back(K(fr_pow2(j * L)));
-                s.push_back(slot_field(src, 0, (j + 1) * L > 128 ? 128 : (j + 1) * L));
+                s.push_back(slot_field(src, 0, (j + 1) * L > 128 ? 128 : (j + 1) * L)); if (j < n - 1) flag(s, 0, CF_GATE);
             }
         }
         int last_shift = (n - 1) * L;
-        if (rem == 1) { s.push_back(Ku(0)); for (int k = 0; k < 3; k++) s.push_back(slot_field(src, last_shift, L)); }
-        else if (rem > 1) {
-            s.push_back(Ku(0)); s.push_back(slot_field(src, last_shift, L));
-            s.push_back(K(fr_pow2(L - rem))); s.push_back(slot_field(src, last_shift, L, L - rem));
+        if (rem == 1) { s.push_back(Ku(0)); flag(s, 0, CF_GATE); for (int k = 0; k < 3; k++) s.push_back(slot_field(src, last_shift, L)); }     // assert_bit
+        else if (rem > 1) {                                // mul(last, 2^(L-rem)), the product looked up
+            s.push_back(Ku(0)); flag(s, 0, CF_GATE); s.push_back(slot_field(src, last_shift, L));
+            s.push_back(K(fr_pow2(L - rem))); s.push_back(slot_field(src, last_shift, L, L - rem)); flag(s, 0, CF_LOOKUP);
         }
     }
     // check_less_than_safe(X, p): range_check(X, rb); [X', p, 1, X'', -2^rb, 1, X]; range_check(X', rb)
     void emit_clt(std::vector<uint32_t> &s, int x, int xp, int xpp) {
         emit_rc(s, x, rb);
-        s.push_back(slot_field(xp, 0, 128)); s.push_back(Ku(GL_P)); s.push_back(Ku(1));
-        s.push_back(slot_field(xpp, 0, 128)); s.push_back(K(fr_neg(fr_pow2(rb)))); s.push_back(Ku(1));
+        s.push_back(slot_field(xp, 0, 128)); flag(s, 0, CF_GATE); s.push_back(Ku(GL_P)); s.push_back(Ku(1));       // gates @0, @3
+        s.push_back(slot_field(xpp, 0, 128)); flag(s, 0, CF_GATE); s.push_back(K(fr_neg(fr_pow2(rb)))); s.push_back(Ku(1));
         s.push_back(slot_field(x, 0, 128));
         emit_rc(s, xp, rb);
     }
     void emit_loadw(std::vector<uint32_t> &s, int x, int xp, int xpp) { s.push_back(slot_field(x, 0, 128)); emit_clt(s, x, xp, xpp); }
     void emit_gate(std::vector<uint32_t> &s) {
-        s.push_back(slot_field(B_C, 0, 128)); s.push_back(slot_field(B_A, 0, 128));
+        s.push_back(slot_field(B_C, 0, 128)); flag(s, 0, CF_GATE); s.push_back(slot_field(B_A, 0, 128));
         s.push_back(slot_field(B_B, 0, 128)); s.push_back(slot_field(B_V, 0, 128));
     }
     void emit_tail(std::vector<uint32_t> &s) {  // base.rs:356-364
         emit_loadw(s, B_X0, B_X0P, B_X0PP);      // quotient
         emit_loadw(s, B_X1, B_X1P, B_X1PP);      // remainder
         s.push_back(Ku(GL_P));                   // load_constant(ORDER)
-        s.push_back(slot_field(B_X1, 0, 128)); s.push_back(slot_field(B_X0, 0, 128)); s.push_back(Ku(GL_P)); s.push_back(slot_field(B_V, 0, 128));
+        s.push_back(slot_field(B_X1, 0, 128)); flag(s, 0, CF_GATE); s.push_back(slot_field(B_X0, 0, 128)); s.push_back(Ku(GL_P)); s.push_back(slot_field(B_V, 0, 128));
     }
     int finish(int id, std::vector<uint32_t> &s, int mode) {
         if ((int)info.size() <= id) info.resize(id + 1, tmpl_info_t{0, 0, 0, 0});
         info[id].slot_base = (uint32_t)slots.size(); info[id].ncells = (uint16_t)s.size(); info[id].mode = (uint8_t)mode;
         slots.insert(slots.end(), s.begin(), s.end());
+        fl.resize(s.size(), 0); slot_flags.insert(slot_flags.end(), fl.begin(), fl.end()); fl.clear();
         return id;
     }
     explicit TemplateTable(int lookup_bits) {

@@ -57,6 +57,10 @@ template <class Sink> struct ValBackend {
     HF Gl bool_as_gl(Bool b) { return b; }
     HF void cell(const fr_t &v) { sink.cell(v); }
     HF void cell64(uint64_t v) { sink.cell(fr_from_u64(v)); }
+    // keygen markers for the NEXT direct cell (no-ops on the device sinks; the shape compiler's PlanSink turns them into the
+    // selector / lookup bitmaps of SURVEY §8f): G = a vertical gate starts there, LK = the cell is registered for the range lookup
+    HF void G() { sink.gate(); }
+    HF void LK() { sink.lookup(); }
 
     // ---------------------------------------------------------------- Goldilocks block records
     HF Gl gl_const(uint64_t k) { sink.rec(T_CONST1, k, 0, 0, 0); return k; }
@@ -85,36 +89,36 @@ template <class Sink> struct ValBackend {
     }
     HNI Gl select(Gl a, Gl b, Bool sel) {      // [a-b, 1, b, a, b, sel, a-b, out]
         fr_t diff = fr_sub(fr_from_u64(a), fr_from_u64(b)); Gl out = sel ? a : b;
-        cell(diff); cell64(1); cell64(b); cell64(a); cell64(b); cell64(sel); cell(diff); cell64(out);
+        G(); cell(diff); cell64(1); cell64(b); cell64(a); G(); cell64(b); cell64(sel); cell(diff); cell64(out);     // gates @0, @4
         return out;
     }
     HF Bool is_zero_cells(const fr_t &a) {    // [z, a, inv, 1, 0, a, z, 0]
         bool z = fr_is_zero(a); fr_t inv = z ? fr_from_u64(1) : inv_small(a);
-        cell64(z ? 1 : 0); cell(a); cell(inv); cell64(1); cell64(0); cell(a); cell64(z ? 1 : 0); cell64(0);
+        G(); cell64(z ? 1 : 0); cell(a); cell(inv); cell64(1); G(); cell64(0); cell(a); cell64(z ? 1 : 0); cell64(0);
         return z ? 1 : 0;
     }
     HNI void idx_to_indicator(Gl idx, int len, Bool *out) {
         fr_t iv = fr_from_u64(idx);
         for (int i = 0; i < len; i++) {
             if (i == 0) out[0] = is_zero_cells(iv);
-            else { fr_t d = fr_sub(iv, fr_from_u64((uint64_t)i)); cell(d); cell64((uint64_t)i); cell64(1); cell(iv); out[i] = is_zero_cells(d); }
+            else { fr_t d = fr_sub(iv, fr_from_u64((uint64_t)i)); G(); cell(d); cell64((uint64_t)i); cell64(1); cell(iv); out[i] = is_zero_cells(d); }
         }
     }
     HNI Gl select_by_indicator(const Gl *a, int stride, const Bool *ind, int len) {   // [0, a0, ind0, s0, ...]
-        u128 sum = 0; cell64(0);
-        for (int i = 0; i < len; i++) { sum += (u128)a[i * stride] * ind[i]; cell64(a[i * stride]); cell64(ind[i]); sink.cell(fr_from_u128(sum)); }
+        u128 sum = 0; if (len > 0) G(); cell64(0);                                   // gates @3i
+        for (int i = 0; i < len; i++) { sum += (u128)a[i * stride] * ind[i]; cell64(a[i * stride]); cell64(ind[i]); if (i + 1 < len) G(); sink.cell(fr_from_u128(sum)); }
         return (uint64_t)sum;
     }
     HNI void num_to_bits(Gl a, int nbits, Bool *out) {     // inner_product(bits, 2^i) then assert_bit per bit
         for (int i = 0; i < nbits; i++) out[i] = i < 64 ? (a >> i) & 1 : 0;
-        cell64(out[0]);
-        for (int i = 1; i < nbits; i++) { cell64(out[i]); sink.cell(fr_pow2(i)); cell64(i >= 63 ? a : (a & ((2ull << i) - 1))); }
-        for (int i = 0; i < nbits; i++) { cell64(0); cell64(out[i]); cell64(out[i]); cell64(out[i]); }
+        if (nbits > 1) G(); cell64(out[0]);                                          // inner product, short form: gates @0, 3, 6, ...
+        for (int i = 1; i < nbits; i++) { cell64(out[i]); sink.cell(fr_pow2(i)); if (i + 1 < nbits) G(); cell64(i >= 63 ? a : (a & ((2ull << i) - 1))); }
+        for (int i = 0; i < nbits; i++) { G(); cell64(0); cell64(out[i]); cell64(out[i]); cell64(out[i]); }   // assert_bit
     }
     HF Gl bits_to_num(const Bool *bits, int n) {          // inner_product(bits, [1,2,4,..])
         if (n <= 0) { cell64(0); return 0; }              // inner_product of nothing: the single cell [0] (cap_height 0)
-        uint64_t acc = bits[0]; cell64(bits[0]);
-        for (int i = 1; i < n; i++) { acc += bits[i] << i; cell64(bits[i]); sink.cell(fr_pow2(i)); cell64(acc); }
+        uint64_t acc = bits[0]; if (n > 1) G(); cell64(bits[0]);
+        for (int i = 1; i < n; i++) { acc += bits[i] << i; cell64(bits[i]); sink.cell(fr_pow2(i)); if (i + 1 < n) G(); cell64(acc); }
         return acc;
     }
     HNI void range_check(Gl a, int bits) {                 // RangeChip::range_check on a 64-bit value
@@ -122,45 +126,45 @@ template <class Sink> struct ValBackend {
         const int n = (bits + L - 1) / L, rem = bits % L; uint64_t last = a;
         const uint64_t lm = (1ull << L) - 1;
         if (n > 1) {
-            cell64(a & lm);
+            G(); LK(); cell64(a & lm);
             for (int j = 1; j < n; j++) {
                 uint64_t limb = (j * L >= 64) ? 0 : (a >> (j * L)) & lm;
-                cell64(limb); sink.cell(fr_pow2(j * L)); cell64((j + 1) * L >= 64 ? a : a & ((1ull << ((j + 1) * L)) - 1));
+                LK(); cell64(limb); sink.cell(fr_pow2(j * L)); if (j + 1 < n) G(); cell64((j + 1) * L >= 64 ? a : a & ((1ull << ((j + 1) * L)) - 1));
                 last = limb;
             }
         }
-        if (rem == 1) { cell64(0); cell64(last); cell64(last); cell64(last); }
-        else if (rem > 1) { cell64(0); cell64(last); sink.cell(fr_pow2(L - rem)); sink.cell(fr_from_u128((u128)last << (L - rem))); }
+        if (rem == 1) { G(); cell64(0); cell64(last); cell64(last); cell64(last); }
+        else if (rem > 1) { G(); cell64(0); cell64(last); sink.cell(fr_pow2(L - rem)); LK(); sink.cell(fr_from_u128((u128)last << (L - rem))); }
     }
     // ---------------------------------------------------------------- native Fr templates (BN254 Poseidon): direct cells
     HF Fr fr_const(const fr_t &v) { cell(v); return v; }
     HF Fr fr_witness(const fr_t &v) { cell(v); return v; }
     HF Fr fr_load_zero() { if (!zero_cached) { cell64(0); zero_cached = true; } return fr_zero(); }
     HF void fr_zero_consts4(Fr *st) { for (int i = 0; i < 4; i++) { cell64(0); st[i] = fr_zero(); } }
-    HNI Fr fr_add(const Fr &a, const Fr &b) { Fr v = h2w::fr_add(a, b); cell(a); cell(b); cell64(1); cell(v); return v; }
-    HNI Fr fr_mul(const Fr &a, const Fr &b) { Fr v = h2w::fr_mul(a, b, cfg.P); cell64(0); cell(a); cell(b); cell(v); return v; }
-    HNI Fr fr_mul_add(const Fr &a, const Fr &b, const Fr &c) { Fr v = h2w::fr_add(h2w::fr_mul(a, b, cfg.P), c); cell(c); cell(a); cell(b); cell(v); return v; }
+    HNI Fr fr_add(const Fr &a, const Fr &b) { Fr v = h2w::fr_add(a, b); G(); cell(a); cell(b); cell64(1); cell(v); return v; }
+    HNI Fr fr_mul(const Fr &a, const Fr &b) { Fr v = h2w::fr_mul(a, b, cfg.P); G(); cell64(0); cell(a); cell(b); cell(v); return v; }
+    HNI Fr fr_mul_add(const Fr &a, const Fr &b, const Fr &c) { Fr v = h2w::fr_add(h2w::fr_mul(a, b, cfg.P), c); G(); cell(c); cell(a); cell(b); cell(v); return v; }
     HNI Fr fr_select(const Fr &a, const Fr &b, Bool sel) {
         Fr diff = fr_sub(a, b); Fr out = sel ? a : b;
-        cell(diff); cell64(1); cell(b); cell(a); cell(b); cell64(sel); cell(diff); cell(out);
+        G(); cell(diff); cell64(1); cell(b); cell(a); G(); cell(b); cell64(sel); cell(diff); cell(out);
         return out;
     }
     HNI Fr fr_select_from_idx(const Fr *col, int n, Gl idx) {
         Bool ind[MAX_CAP]; idx_to_indicator(idx, n, ind);
-        Fr sum = fr_zero(); cell64(0);
-        for (int i = 0; i < n; i++) { if (ind[i]) sum = h2w::fr_add(sum, col[i]); cell(col[i]); cell64(ind[i]); cell(sum); }
+        Fr sum = fr_zero(); if (n > 0) G(); cell64(0);
+        for (int i = 0; i < n; i++) { if (ind[i]) sum = h2w::fr_add(sum, col[i]); cell(col[i]); cell64(ind[i]); if (i + 1 < n) G(); cell(sum); }
         return sum;
     }
     HF Fr limbs_to_num(const Gl *in, int n) {             // RangeChip::limbs_to_num(limbs, 64)
-        Fr acc = fr_zero(); acc.l[0] = in[0]; cell64(in[0]);
-        for (int i = 1; i < n; i++) { acc.l[i] = in[i]; cell64(in[i]); sink.cell(fr_pow2(64 * i)); cell(acc); }
+        Fr acc = fr_zero(); acc.l[0] = in[0]; if (n > 1) G(); cell64(in[0]);
+        for (int i = 1; i < n; i++) { acc.l[i] = in[i]; cell64(in[i]); sink.cell(fr_pow2(64 * i)); if (i + 1 < n) G(); cell(acc); }
         return acc;
     }
     HNI void decompose_le_56_5(const Fr &x, Gl *out) {     // RangeChip::decompose_le(x, 56, 5)
         for (int i = 0; i < 5; i++) out[i] = fr_bits(x, 56 * i, 56);
-        cell64(out[0]);
+        G(); cell64(out[0]);
         for (int i = 1; i < 5; i++) {
-            cell64(out[i]); sink.cell(fr_pow2(56 * i));
+            cell64(out[i]); sink.cell(fr_pow2(56 * i)); if (i < 4) G();
             Fr acc = x; const int hb = 56 * (i + 1);                 // x mod 2^(56(i+1))
             if (hb < 256) { const int w = hb >> 6, sh = hb & 63; for (int j = w + 1; j < 4; j++) acc.l[j] = 0; acc.l[w] &= sh ? ((1ull << sh) - 1) : 0; }
             cell(acc);
@@ -230,6 +234,8 @@ struct DevSink {
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells;
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }
     HF void cell(const fr_t &v) { g_store_fr(out + cell_off, v); cell_off++; }
+    HF void gate() {}
+    HF void lookup() {}
     HF void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     HF void merkle_begin(int, int, bool, uint64_t) {}
     HF void merkle_end(int, int, bool) {}

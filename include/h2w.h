@@ -171,6 +171,27 @@ int h2w_fri_witness_batch(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_pro
  * waits for it).  Lets a caller give the latency-bound value strands and the streaming kernel differently CU-masked streams. */
 int h2w_fri_witness_batch2(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs,
                            void *advice_dev, void *workspace_dev, void *stream, void *emit_stream);
+/* ---- the consumer-side format of the advice stream -------------------------------------------
+ * The cell stream of a shape is static, so its keygen metadata is too.  Restates (halo2-lib `community-edition`, not in
+ * /root/reference; semantics [R]): Context::selector (one bit per cell: a vertical gate starts there),
+ * the range-lookup registrations (RangeChip::range_check -> cells_to_lookup, in registration order), the FlexGate
+ * break points (gates/flex_gate/threads: assign_with_constraints) and the column assignment of the witness
+ * (assign_witnesses) incl. the lookup-advice columns.  Copy-constraint lists are NOT produced (next). */
+uint64_t h2w_plan_num_gates(h2w_plan *);
+uint64_t h2w_plan_num_lookups(h2w_plan *);
+int h2w_plan_selectors(h2w_plan *, uint8_t *bitmap /* (num_cells + 7) / 8 bytes, bit i = cell i */);
+int h2w_plan_lookup_cells(h2w_plan *, uint64_t *cells /* num_lookups */);
+/* break_points[c] = last used row of column c (the cell there is repeated at row 0 of column c + 1); max_rows = 2^k - unusable_rows.
+ * out may be NULL to query *n_out. */
+int h2w_break_points(const uint8_t *selectors, uint64_t n_cells, int k, int unusable_rows,
+                     uint64_t *out, uint64_t cap, uint64_t *n_out);
+/* flat advice (device) -> columns[n_proofs][n_bp + 1][2^k] (device, 32-byte canonical Fr, unassigned rows zero) */
+int h2w_layout_columns(const void *advice_dev, uint64_t n_cells, uint64_t proof_stride_cells, uint64_t n_proofs,
+                       const uint64_t *break_points, uint64_t n_bp, int k, void *columns_dev, void *stream);
+/* lookup advice columns: out[n_proofs][*n_cols_out][2^k]; out_dev may be NULL to query *n_cols_out */
+int h2w_layout_lookup_columns(h2w_plan *, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs,
+                              int k, int unusable_rows, void *out_dev, uint64_t *n_cols_out, void *stream);
+
 /* Per-proof device status words (0 = ok; non-zero = reference would have panicked, e.g. inverse of zero) */
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */

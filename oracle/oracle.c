@@ -1174,5 +1174,48 @@ void orc_fr_mul(const ofr_t *a, const ofr_t *b, ofr_t *out) { fr_init(); *out = 
 void orc_fr_inv(const ofr_t *a, ofr_t *out) { fr_init(); *out = fr_inv(a); }
 void orc_fr_modulus(ofr_t *out) { *out = FR_MOD; }
 
+/* ===================================================================== keygen metadata + FlexGate column layout
+ * halo2-lib `community-edition` (not in /root/reference) semantics [R]:
+ *  - gates/flex_gate/threads/single_phase.rs assign_with_constraints::<F, ROTATIONS = 4>: walk ctx.advice down column `gate_index`;
+ *    `if (q && row_offset + ROTATIONS > max_rows) || row_offset >= max_rows - 1 { break_points.push(row_offset); row_offset = 0;
+ *    gate_index += 1; assign the same value again at (gate_index, 0) + copy constraint }`, then enable q at the current row.
+ *  - assign_witnesses: the same walk driven by the pinned break points.
+ *  - lookup advice: cells_to_lookup copied in order down lookup columns of max_rows rows.
+ *  max_rows = 2^k - unusable_rows (base_test: 9). */
+uint64_t orc_num_gates(const octx_t *c) { uint64_t n = 0; for (size_t i = 0; i < c->n && i < c->selcap; i++) n += c->selector[i]; return n; }
+void orc_selector_bitmap(const octx_t *c, uint8_t *out) {
+    memset(out, 0, (c->n + 7) / 8);
+    for (size_t i = 0; i < c->n && i < c->selcap; i++) if (c->selector[i]) out[i / 8] |= (uint8_t)(1u << (i & 7));
+}
+uint64_t orc_num_lookups(const octx_t *c) { return c->nlookup; }
+void orc_lookup_cells(const octx_t *c, uint64_t *out) { for (size_t i = 0; i < c->nlookup; i++) out[i] = (uint64_t)c->lookup[i].cell; }
+uint64_t orc_break_points(const octx_t *c, int k, int unusable_rows, uint64_t *out, uint64_t cap) {
+    const uint64_t max_rows = ((uint64_t)1 << k) - (uint64_t)unusable_rows; uint64_t row = 0, n = 0;
+    for (size_t i = 0; i < c->n; i++) {
+        int q = i < c->selcap ? c->selector[i] : 0;
+        if ((q && row + 4 > max_rows) || row >= max_rows - 1) { if (out && n < cap) out[n] = row; n++; row = 0; }
+        row++;
+    }
+    return n;
+}
+/* columns[(n_bp + 1)][2^k] from the pinned break points (assign_witnesses); unassigned rows are zero */
+void orc_layout_columns(const octx_t *c, const uint64_t *bp, uint64_t n_bp, int k, ofr_t *out) {
+    const uint64_t rows = (uint64_t)1 << k; uint64_t col = 0, row = 0, nb = 0;
+    memset(out, 0, (size_t)((n_bp + 1) * rows) * sizeof(ofr_t));
+    for (size_t i = 0; i < c->n; i++) {
+        out[col * rows + row] = c->advice[i];
+        if (nb < n_bp && bp[nb] == row) { nb++; row = 0; col++; out[col * rows + row] = c->advice[i]; }
+        row++;
+    }
+}
+uint64_t orc_layout_lookup_columns(const octx_t *c, int k, int unusable_rows, ofr_t *out) {
+    const uint64_t rows = (uint64_t)1 << k, max_rows = rows - (uint64_t)unusable_rows, ncols = (c->nlookup + max_rows - 1) / max_rows;
+    if (!out) return ncols;
+    memset(out, 0, (size_t)(ncols * rows) * sizeof(ofr_t));
+    uint64_t col = 0, row = 0;
+    for (size_t i = 0; i < c->nlookup; i++) { if (row >= max_rows) { row = 0; col++; } out[col * rows + row] = c->advice[c->lookup[i].cell]; row++; }
+    return ncols;
+}
+
 /* ===================================================================== native FRI prover (valid synthetic proofs) */
 #include "prover.inc"

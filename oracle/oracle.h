@@ -81,6 +81,15 @@ int orc_mock_prover(const octx_t *, uint64_t *gates, uint64_t *equalities, uint6
 /* scope tree dump: writes "path cells\n" lines (inclusive counts) into buf; returns bytes needed */
 size_t orc_scope_dump(const octx_t *, char *buf, size_t cap);
 
+/* --- keygen metadata + FlexGate column layout (needs witness_gen_only = 0); halo2-lib semantics [R], see oracle.c --- */
+uint64_t orc_num_gates(const octx_t *);
+void orc_selector_bitmap(const octx_t *, uint8_t *out /* (num_cells + 7) / 8 */);
+uint64_t orc_num_lookups(const octx_t *);
+void orc_lookup_cells(const octx_t *, uint64_t *out);
+uint64_t orc_break_points(const octx_t *, int k, int unusable_rows, uint64_t *out, uint64_t cap);
+void orc_layout_columns(const octx_t *, const uint64_t *bp, uint64_t n_bp, int k, ofr_t *out);
+uint64_t orc_layout_lookup_columns(const octx_t *, int k, int unusable_rows, ofr_t *out);
+
 /* --- synthetic inputs (splitmix64-seeded) --- */
 void orc_synth_consts(oconsts_t *out, uint64_t seed);
 size_t orc_proof_words(const oshape_t *);                      /* number of u64 words in the flat proof */

@@ -97,6 +97,13 @@ def lib():
     L.orc_proof_words.restype = C.c_size_t
     L.orc_proof_words.argtypes = [C.POINTER(Shape)]
     L.orc_synth_proof.argtypes = [C.POINTER(Shape), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_num_gates.restype = C.c_uint64; L.orc_num_gates.argtypes = [vp]
+    L.orc_selector_bitmap.argtypes = [vp, vp]
+    L.orc_num_lookups.restype = C.c_uint64; L.orc_num_lookups.argtypes = [vp]
+    L.orc_lookup_cells.argtypes = [vp, vp]
+    L.orc_break_points.restype = C.c_uint64; L.orc_break_points.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
+    L.orc_layout_columns.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
+    L.orc_layout_lookup_columns.restype = C.c_uint64; L.orc_layout_lookup_columns.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orc_prove_fri.restype = C.c_int
     L.orc_prove_fri.argtypes = [C.POINTER(Shape), C.POINTER(Consts), C.c_uint64, C.POINTER(C.c_uint64)]
     L.orc_nv_gl_permute.argtypes = [C.POINTER(Consts), C.POINTER(C.c_uint64)]
@@ -183,6 +190,35 @@ class Ctx:
             path, cells = line.rsplit(" ", 1)
             out[path] = int(cells)
         return out
+
+    # keygen metadata / column layout (witness_gen_only=False contexts)
+    def selectors(self):
+        buf = (C.c_uint8 * ((self.num_cells() + 7) // 8))()
+        self.L.orc_selector_bitmap(self.p, buf)
+        return bytes(buf)
+
+    def lookup_cells(self):
+        n = int(self.L.orc_num_lookups(self.p))
+        buf = (C.c_uint64 * max(n, 1))()
+        self.L.orc_lookup_cells(self.p, buf)
+        return list(buf[:n])
+
+    def break_points(self, k, unusable_rows=9):
+        n = int(self.L.orc_break_points(self.p, k, unusable_rows, None, 0))
+        buf = (C.c_uint64 * max(n, 1))()
+        self.L.orc_break_points(self.p, k, unusable_rows, buf, n)
+        return list(buf[:n])
+
+    def layout_columns(self, bp, k):
+        out = (Fr * ((len(bp) + 1) << k))()
+        self.L.orc_layout_columns(self.p, (C.c_uint64 * max(len(bp), 1))(*bp), len(bp), k, out)
+        return bytes(out)
+
+    def layout_lookup_columns(self, k, unusable_rows=9):
+        n = int(self.L.orc_layout_lookup_columns(self.p, k, unusable_rows, None))
+        out = (Fr * max(n << k, 1))()
+        self.L.orc_layout_lookup_columns(self.p, k, unusable_rows, out)
+        return n, bytes(out)[:(n << k) * 32]
 
     def mock_prover(self):
         g, e, l, s = (C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64())

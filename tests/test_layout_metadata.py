@@ -1,0 +1,112 @@
+"""keygen-side metadata of the cell stream and the FlexGate column layout.
+
+Host part (no GPU): the product's selector bitmap, lookup registrations (in order) and break points — produced by the shape
+compiler from template slot flags and the backend's gate/lookup markers — against the oracle, which records them the
+halo2-base way (Context::assign_region gate offsets, RangeChip::range_check -> cells_to_lookup).  The semantics of the
+third-party halo2-lib are restated from recollection ([R], oracle.c) — "parity unpinned" like the rest of that boundary.
+GPU part: the column / lookup-column kernels against the oracle's restated assign_witnesses."""
+import numpy as np
+import pytest
+
+SHAPES = [dict(d=6, q=2), dict(d=7, q=3, rb=2), dict(d=6, q=2, n_perm_z=0), dict(d=6, q=1, cap=0),
+          dict(d=8, q=2, rb=2, cap=2, arity_bits=2, final_poly_bits=3), dict(d=6, q=2, pow_bits=10, n_cols=6, n_quotient=4, n_pis=1, num_challenges=3)]
+
+
+def _shapes(h2w, oracle, mode, lookup_bits, kw):
+    kw = dict(kw)
+    args = dict(rate_bits=kw.pop("rb", 1), cap_height=kw.pop("cap", 4), hash_mode=mode, lookup_bits=lookup_bits)
+    d, q = kw.pop("d"), kw.pop("q")
+    sh, osh = h2w.fibonacci_shape(d, q, **args), oracle.fibonacci_shape(d, q, **args)
+    for k, v in kw.items():
+        setattr(sh, k, v); setattr(osh, k, v)
+    return sh, osh
+
+
+def _oracle_ctx(oracle, osh, ko, seed=3):
+    ctx = oracle.Ctx(osh.lookup_bits, witness_gen_only=False)
+    assert oracle.verify_stark(ctx, osh, ko, oracle.synth_proof(osh, seed)) == 0
+    return ctx
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("lookup_bits", [21, 13, 8])
+def test_selectors_lookups_break_points_match_oracle(h2w, h2w_api, oracle, consts, mode, lookup_bits):
+    ko, kh = consts
+    for kw in (SHAPES if lookup_bits == 21 else SHAPES[:2]):
+        sh, osh = _shapes(h2w, oracle, mode, lookup_bits, kw)
+        plan = h2w_api.Plan(sh, kh)
+        ctx = _oracle_ctx(oracle, osh, ko)
+        assert plan.num_cells == ctx.num_cells()
+        assert plan.selectors() == ctx.selectors(), kw
+        assert plan.lookup_cells() == ctx.lookup_cells(), kw
+        mp = ctx.mock_prover()
+        assert mp["gates"] == int(plan.L.h2w_plan_num_gates(plan.p)) and mp["lookups"] == len(plan.lookup_cells())
+        for k in (12, 15, 18):
+            bp = plan.break_points(k)
+            assert bp == ctx.break_points(k), (kw, k)
+            # invariants of the packing: every column within max_rows, no gate straddles a break, the stream is covered once
+            max_rows = (1 << k) - 9
+            assert all(b + 1 <= max_rows for b in bp)
+            used = sum(b + 1 for b in bp) - len(bp)
+            assert 0 < plan.num_cells - used <= max_rows
+            sel = np.unpackbits(np.frombuffer(plan.selectors(), dtype=np.uint8), bitorder="little")
+            pos = 0
+            for b in bp:                      # cells pos..pos+b live in this column; a gate starting at cell i needs rows i..i+3
+                seg = sel[pos:pos + b + 1]
+                gates = np.nonzero(seg)[0]
+                assert gates.size == 0 or gates[-1] + 3 <= b or gates[-1] == b, (kw, k)   # the breaking cell's gate moves to the next column
+                pos += b
+        ctx.close(); plan.close()
+
+
+def test_metadata_api_errors(h2w, h2w_api, consts):
+    ko, kh = consts
+    import ctypes as C
+    L = h2w.lib()
+    n = C.c_uint64()
+    assert L.h2w_break_points(None, 10, 12, 9, None, 0, C.byref(n)) != 0
+    assert L.h2w_break_points((C.c_uint8 * 2)(), 10, 2, 9, None, 0, C.byref(n)) != 0          # k too small
+    assert L.h2w_plan_selectors(None, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_column_layout_on_device(h2w, h2w_api, oracle, consts, mode):
+    import torch
+    ko, kh = consts
+    sh, osh = _shapes(h2w, oracle, mode, 21, dict(d=6, q=2))
+    plan = h2w_api.Plan(sh, kh)
+    seeds = [5, 6]
+    proofs = [oracle.synth_proof(osh, s) for s in seeds]
+    host = torch.empty(len(seeds) * plan.proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda()
+    n = len(seeds)
+    advice = torch.zeros(n * plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), stream)
+    for k in (14, 17):
+        bp = plan.break_points(k)
+        ncol = len(bp) + 1
+        cols = torch.full((((n * ncol) << k) * 32,), 0xAB, dtype=torch.uint8, device="cuda")          # poisoned: unassigned rows must come back zero
+        plan.layout_columns(advice.data_ptr(), n, bp, k, cols.data_ptr(), stream)
+        nl = plan.num_lookup_columns(k)
+        lk = torch.full((((n * nl) << k) * 32,), 0xCD, dtype=torch.uint8, device="cuda")
+        assert plan.layout_lookup_columns(advice.data_ptr(), n, k, lk.data_ptr(), stream=stream) == nl
+        torch.cuda.synchronize()
+        got, gotl = cols.cpu().numpy().tobytes(), lk.cpu().numpy().tobytes()
+        for i, p in enumerate(proofs):
+            ctx = oracle.Ctx(21, witness_gen_only=False)
+            assert oracle.verify_stark(ctx, osh, ko, p) == 0
+            assert ctx.break_points(k) == bp
+            want = ctx.layout_columns(bp, k)
+            sz = (ncol << k) * 32
+            assert got[i * sz:(i + 1) * sz] == want, (k, i)
+            onl, wantl = ctx.layout_lookup_columns(k)
+            assert onl == nl
+            szl = (nl << k) * 32
+            assert gotl[i * szl:(i + 1) * szl] == wantl, (k, i)
+            ctx.close()
+    plan.close()
