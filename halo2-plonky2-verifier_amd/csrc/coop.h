@@ -357,7 +357,8 @@ struct QuadSink {
             W(q, c); W(q + 1, s); W(q + 2, c); W64(q + 3, 1); W(q + 4, ns);
             if (p >= 0) s = ns;
         };
-        auto ark = [&](int it) { need(20); add_const(5 * l, bnk(0, BK_C + it + l)); so += 20; };
+        // (constants are requested before a possible flush, see the partial rounds)
+        auto ark = [&](int it) { const fr_t kc = bnk(0, BK_C + it + l); need(20); add_const(5 * l, kc); so += 20; };
         auto mix = [&](int which) {                      // which 0: M, 1: P
             if (!zc) { need(1); W64(l == 0 ? 0 : -64, 0); so += 1; zc = true; }
             need(64);
@@ -378,22 +379,26 @@ struct QuadSink {
         for (int half = 0; half < 2; half++) {
             if (half == 1) {
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                    // This round's constants are fetched BEFORE the flush of the previous round's cells: loads and stores share vmcnt
+                    // in order, so a constant requested after the flush's stores would wait for all of them to reach memory.
+                    const int ix = (BN_WIDTH * 2 - 1) * r + l, lm = l > 0 ? l - 1 : 0, iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + lm;
+                    const fr_t kc = bnk(0, BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r);
+                    const fr_t ksx = bnk(0, BK_S + ix), ksxm = bnk(1, BK_S + ix), ksy = bnk(0, BK_S + iy), ksym = bnk(1, BK_S + iy);
                     need(52);
-                    exp5(l == 0 ? 0 : -64); add_const(l == 0 ? 12 : -64, bnk(0, BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r));
+                    exp5(l == 0 ? 0 : -64); add_const(l == 0 ? 12 : -64, kc);
                     so += 17;
                     const fr_t s0 = shfl4(s, 0);
-                    const int ix = (BN_WIDTH * 2 - 1) * r + l;
-                    const fr_t pr = fr_mont_mul(s, bnk(1, BK_S + ix), ninv);            // S[j] * s_j (lane 0: new s0)
+                    const fr_t pr = fr_mont_mul(s, ksxm, ninv);                         // S[j] * s_j (lane 0: new s0)
                     fr_t incl = pr, t = shfl4_up(incl, 1); if (l >= 1) incl = fr_add(incl, t);
                     t = shfl4_up(incl, 2); if (l >= 2) incl = fr_add(incl, t);
                     fr_t excl = shfl4_up(incl, 1); if (l == 0) excl = fr_zero();
-                    { const int p = 5 * l; W(p, bnk(0, BK_S + ix)); W(p + 1, excl); W(p + 2, bnk(0, BK_S + ix)); W(p + 3, s); W(p + 4, incl); }
+                    { const int p = 5 * l; W(p, ksx); W(p + 1, excl); W(p + 2, ksx); W(p + 3, s); W(p + 4, incl); }
                     so += 20;
                     const fr_t ns0 = shfl4(incl, 3);
                     {
-                        const int lm = l > 0 ? l - 1 : 0, iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + lm, p = l > 0 ? 5 * lm : -64;
-                        const fr_t nv = fr_add(fr_mont_mul(s0, bnk(1, BK_S + iy), ninv), s);
-                        W(p, bnk(0, BK_S + iy)); W(p + 1, s); W(p + 2, bnk(0, BK_S + iy)); W(p + 3, s0); W(p + 4, nv);
+                        const int p = l > 0 ? 5 * lm : -64;
+                        const fr_t nv = fr_add(fr_mont_mul(s0, ksym, ninv), s);
+                        W(p, ksy); W(p + 1, s); W(p + 2, ksy); W(p + 3, s0); W(p + 4, nv);
                         s = l > 0 ? nv : ns0;
                     }
                     so += 15;
