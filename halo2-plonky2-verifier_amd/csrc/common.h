@@ -27,7 +27,7 @@ struct ExpandArgs {
 };
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
 
-constexpr int MAX_SLOTS = 1536;
+constexpr int MAX_SLOTS = 1536;   // limits of a plan's template table (the default expansion kernel sizes its LDS copy dynamically)
 constexpr int MAX_CONSTS = 96;
 
 // device copies of a TemplateTable

@@ -17,9 +17,13 @@ constexpr int EXPAND_THREADS = 256;
 typedef unsigned long long ull;
 struct __attribute__((aligned(16))) u128s { ull lo, hi; };
 
+// LDS of a block: the template tables are sized by what the plan's lookup_bits needs (dynamic LDS: ~2.2 KB at lookup_bits 21, the
+// static MAX_* worst case would be 9 KB) — the expansion kernel shares its CUs with the strand kernels of other batches, whose
+// staging regions hold most of the LDS, and every 16 KB block that does not fit is four fewer wavefronts streaming.
+extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_tables[];
 template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_t(ExpandArgs A) {
-    __shared__ uint32_t s_slots[MAX_SLOTS];
-    __shared__ u128s s_consts[MAX_CONSTS * 2];
+    u128s *s_consts = reinterpret_cast<u128s *>(s_dyn_tables);
+    uint32_t *s_slots = reinterpret_cast<uint32_t *>(s_consts + A.nconsts * 2);
     __shared__ tmpl_info_t s_info[T_MAX];
     __shared__ u128s s_bases[TILE_RECS][B_COUNT];
     __shared__ uint32_t s_pre[TILE_RECS + 1];
@@ -308,17 +312,19 @@ static int expand_variant() { static int v = -1; if (v < 0) { const char *e = ge
 
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
     if (A.nrec == 0 || nproofs == 0) return;
-    const int TILE_RECS = expand_variant() == 64 ? 64 : (expand_variant() == 1 || expand_variant() == 2) ? 64 : 32;
+    const int TILE_RECS = expand_variant() == 16 ? 16 : expand_variant() == 64 ? 64 : (expand_variant() == 1 || expand_variant() == 2) ? 64 : 32;
     uint64_t ntiles = (A.nrec + TILE_RECS - 1) / TILE_RECS;
     { static int ov = -2; if (ov == -2) { const char *e = getenv("H2W_EXPAND_BLOCKS"); ov = e ? atoi(e) : -1; } if (ov > 0) grid_x = (int)((uint64_t)ov / nproofs) + 1; }
     uint64_t gx = (uint64_t)grid_x; if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)nproofs);
+    const size_t dyn = ((size_t)A.nconsts * 32 + (size_t)A.nslots * 4 + 15) & ~(size_t)15;      // expand_kernel_t's tables
     if (expand_variant() == 2) hipLaunchKernelGGL(expand_kernel_r, grid, dim3(EXPAND_THREADS), 0, stream, A);
     else if (expand_variant() == 1) hipLaunchKernelGGL(expand_kernel_w, grid, dim3(EXPAND_THREADS), 0, stream, A);
-    else if (expand_variant() == 11) hipLaunchKernelGGL((expand_kernel_t<1, 32, 5>), grid, dim3(EXPAND_THREADS), 0, stream, A);
-    else if (expand_variant() == 12) hipLaunchKernelGGL((expand_kernel_t<2, 32, 5>), grid, dim3(EXPAND_THREADS), 0, stream, A);
-    else if (expand_variant() == 64) hipLaunchKernelGGL((expand_kernel_t<0, 64, 6>), grid, dim3(EXPAND_THREADS), 0, stream, A);
-    else hipLaunchKernelGGL((expand_kernel_t<0, 32, 5>), grid, dim3(EXPAND_THREADS), 0, stream, A);
+    else if (expand_variant() == 11) hipLaunchKernelGGL((expand_kernel_t<1, 32, 5>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
+    else if (expand_variant() == 12) hipLaunchKernelGGL((expand_kernel_t<2, 32, 5>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
+    else if (expand_variant() == 64) hipLaunchKernelGGL((expand_kernel_t<0, 64, 6>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
+    else if (expand_variant() == 16) hipLaunchKernelGGL((expand_kernel_t<0, 16, 4>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
+    else hipLaunchKernelGGL((expand_kernel_t<0, 32, 5>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
 }
 
 }  // namespace h2w
