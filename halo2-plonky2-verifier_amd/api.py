@@ -238,6 +238,12 @@ class Plan:
         _ck(self.L.h2w_layout_lookup_columns(self.p, advice_ptr, self.num_cells if proof_stride is None else proof_stride, n, k, unusable_rows, out_ptr, C.byref(nc), stream), "h2w_layout_lookup_columns")
         return int(nc.value)
 
+    def check_constraints(self, advice_ptr, n, stream=0, proof_stride=None):
+        """(failed gates, out-of-range lookups) over n advice streams, checked on the device."""
+        bad = (C.c_uint64 * 2)()
+        _ck(self.L.h2w_check_constraints(self.p, advice_ptr, self.num_cells if proof_stride is None else proof_stride, n, bad, stream), "h2w_check_constraints")
+        return int(bad[0]), int(bad[1])
+
     def timing(self, back=0):
         """(prologue ms, strands ms, BN254-unit ms, expansion-kernel ms, total ms) of the batch call `back` calls before
         the last, from HIP events recorded on the call's stream."""

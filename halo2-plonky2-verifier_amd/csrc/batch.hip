@@ -373,7 +373,7 @@ struct h2w_plan {
     LoadItem *d_items = nullptr; uint32_t n_items = 0; uint64_t load_nrec = 0, load_ncell = 0;
     BnConsts h_bn[2];
     h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
-    bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr;
+    bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
@@ -492,6 +492,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->d_lookup_cells) (void)hipFree(p->d_lookup_cells);
+    if (p->d_sel_bits) (void)hipFree(p->d_sel_bits);
     if (p->ev_ready) (void)hipEventDestroy(p->t_done);
     if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
@@ -680,6 +681,7 @@ __global__ void k_layout_lookup(const ulonglong2 *advice, uint64_t proof_stride,
         out[(uint64_t)p * total2 + h] = v;
     }
 }
+static int ensure_lookup_cells(h2w_plan *p);
 int h2w_layout_lookup_columns(h2w_plan *p, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs, int k, int unusable_rows, void *out_dev, uint64_t *n_cols_out, void *stream_) {
     if (!p || k < 3 || k > 34 || unusable_rows < 0) { set_error("h2w_layout_lookup_columns: bad argument"); return -1; }
     if (h2w_plan_metadata(p) != 0) return -1;
@@ -688,17 +690,68 @@ int h2w_layout_lookup_columns(h2w_plan *p, const void *advice_dev, uint64_t proo
     if (!out_dev) return 0;                    // size query
     if (!advice_dev) { set_error("h2w_layout_lookup_columns: null advice"); return -1; }
     if (p->device < 0) { set_error("h2w_layout_lookup_columns: no HIP device"); return -1; }
-    if (p->ncells >> 32) { set_error("h2w_layout_lookup_columns: stream longer than 2^32 cells"); return -1; }
     hipStream_t stream = (hipStream_t)stream_;
-    if (!p->d_lookup_cells && p->n_lookups) {
-        std::vector<uint32_t> h((size_t)p->n_lookups); uint64_t k2 = 0;
-        for (uint64_t i = 0; i < p->ncells; i++) if (p->lk_bits[i / 8] >> (i & 7) & 1) h[k2++] = (uint32_t)i;
-        H2W_HIP(hipMalloc((void **)&p->d_lookup_cells, h.size() * sizeof(uint32_t)));
-        H2W_HIP(hipMemcpy(p->d_lookup_cells, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
+    if (ensure_lookup_cells(p) != 0) return -1;
     if (n_proofs == 0 || ncols == 0) return 0;
     hipLaunchKernelGGL(k_layout_lookup, dim3(4096, (unsigned)n_proofs), dim3(256), 0, stream, (const ulonglong2 *)advice_dev, proof_stride_cells, p->d_lookup_cells, p->n_lookups, max_rows, (uint32_t)ncols, (uint32_t)k, (ulonglong2 *)out_dev);
     H2W_HIP(hipGetLastError());
+    return 0;
+}
+// Device-side constraint check of an advice stream (the MockProver's gate and lookup checks, restated): every vertical gate
+// a[i] + a[i+1]*a[i+2] = a[i+3] at a selector-enabled cell i, and every looked-up cell < 2^lookup_bits.  Size-independent: it
+// covers every cell of a full-size stream without the CPU oracle.  Copy constraints are not checked (no equality lists yet).
+__global__ void k_check_gates(const fr_t *advice, uint64_t proof_stride, uint64_t n_cells, const uint8_t *sel, FrParams P, unsigned long long *bad) {
+    const uint32_t p = blockIdx.y; const fr_t *adv = advice + (uint64_t)p * proof_stride; unsigned long long nb = 0;
+    for (uint64_t byte = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; byte < (n_cells + 7) / 8; byte += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t m = sel[byte];
+        while (m) {
+            const int b = __ffs((int)m) - 1; m &= m - 1; const uint64_t i = byte * 8 + (uint64_t)b;
+            if (i + 3 >= n_cells) { nb++; continue; }
+            const fr_t a = g_load_fr(adv + i), x = g_load_fr(adv + i + 1), y = g_load_fr(adv + i + 2), d = g_load_fr(adv + i + 3);
+            if (!fr_eq(fr_add(a, fr_mul(x, y, P)), d)) nb++;
+        }
+    }
+    if (nb) atomicAdd(bad, nb);
+}
+__global__ void k_check_lookups(const fr_t *advice, uint64_t proof_stride, const uint32_t *cells, uint64_t n_lookups, int lookup_bits, unsigned long long *bad) {
+    const uint32_t p = blockIdx.y; const fr_t *adv = advice + (uint64_t)p * proof_stride; unsigned long long nb = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_lookups; j += (uint64_t)gridDim.x * blockDim.x) {
+        const fr_t v = g_load_fr(adv + cells[j]);
+        if ((v.l[1] | v.l[2] | v.l[3]) != 0 || (v.l[0] >> lookup_bits) != 0) nb++;
+    }
+    if (nb) atomicAdd(bad + 1, nb);
+}
+static int ensure_lookup_cells(h2w_plan *p) {
+    if (p->d_lookup_cells || !p->n_lookups) return 0;
+    if (p->ncells >> 32) { set_error("lookup cells: stream longer than 2^32 cells"); return -1; }
+    std::vector<uint32_t> h((size_t)p->n_lookups); uint64_t k2 = 0;
+    for (uint64_t i = 0; i < p->ncells; i++) if (p->lk_bits[i / 8] >> (i & 7) & 1) h[k2++] = (uint32_t)i;
+    H2W_HIP(hipMalloc((void **)&p->d_lookup_cells, h.size() * sizeof(uint32_t)));
+    H2W_HIP(hipMemcpy(p->d_lookup_cells, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+int h2w_check_constraints(h2w_plan *p, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs, uint64_t bad_out[2], void *stream_) {
+    if (!p || !advice_dev || !bad_out) { set_error("h2w_check_constraints: null argument"); return -1; }
+    if (p->device < 0) { set_error("h2w_check_constraints: no HIP device"); return -1; }
+    if (h2w_plan_metadata(p) != 0 || ensure_lookup_cells(p) != 0) return -1;
+    bad_out[0] = bad_out[1] = 0;
+    if (n_proofs == 0) return 0;
+    if (n_proofs > 65535) { set_error("h2w_check_constraints: too many proofs per call"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p->d_sel_bits) {
+        H2W_HIP(hipMalloc((void **)&p->d_sel_bits, p->sel_bits.size()));
+        H2W_HIP(hipMemcpy(p->d_sel_bits, p->sel_bits.data(), p->sel_bits.size(), hipMemcpyHostToDevice));
+    }
+    unsigned long long *d_bad = nullptr;
+    H2W_HIP(hipMallocAsync((void **)&d_bad, 16, stream));
+    H2W_HIP(hipMemsetAsync(d_bad, 0, 16, stream));
+    hipLaunchKernelGGL(k_check_gates, dim3(2048, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, p->ncells, p->d_sel_bits, p->P, d_bad);
+    if (p->n_lookups) hipLaunchKernelGGL(k_check_lookups, dim3(1024, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, p->d_lookup_cells, p->n_lookups, (int)p->shape.lookup_bits, d_bad);
+    unsigned long long h[2] = {0, 0};
+    H2W_HIP(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, stream));
+    H2W_HIP(hipStreamSynchronize(stream));
+    H2W_HIP(hipFreeAsync(d_bad, stream));
+    bad_out[0] = h[0]; bad_out[1] = h[1];
     return 0;
 }
 int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {

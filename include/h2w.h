@@ -192,6 +192,12 @@ int h2w_layout_columns(const void *advice_dev, uint64_t n_cells, uint64_t proof_
 int h2w_layout_lookup_columns(h2w_plan *, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs,
                               int k, int unusable_rows, void *out_dev, uint64_t *n_cols_out, void *stream);
 
+/* Device-side constraint check of advice streams (restated MockProver gate + lookup checks): bad[0] = vertical
+ * gates a[i] + a[i+1]*a[i+2] != a[i+3] over the selector-enabled cells, bad[1] = looked-up cells >= 2^lookup_bits, summed over
+ * the n_proofs streams.  Synchronises the stream.  Covers every cell of full-size streams without the CPU oracle. */
+int h2w_check_constraints(h2w_plan *, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs,
+                          uint64_t bad[2], void *stream);
+
 /* Per-proof device status words (0 = ok; non-zero = reference would have panicked, e.g. inverse of zero) */
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */

@@ -110,3 +110,73 @@ def test_column_layout_on_device(h2w, h2w_api, oracle, consts, mode):
             assert gotl[i * szl:(i + 1) * szl] == wantl, (k, i)
             ctx.close()
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_device_constraint_check(h2w, h2w_api, oracle, consts, mode):
+    """h2w_check_constraints: all gates and lookups of the GPU-generated stream hold (same counts as the oracle's MockProver
+    checks), and it notices a corrupted cell."""
+    import torch
+    ko, kh = consts
+    sh, osh = _shapes(h2w, oracle, mode, 21, dict(d=7, q=3, rb=2))
+    plan = h2w_api.Plan(sh, kh)
+    n = 2
+    proofs = [oracle.synth_proof(osh, s) for s in (8, 9)]
+    host = torch.empty(n * plan.proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda()
+    advice = torch.zeros(n * plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), stream)
+    # random proofs fail the PoW range check (a SEMANTIC lookup: the response has no leading zeros), nothing else
+    ctx = _oracle_ctx(oracle, osh, ko, 8)
+    mp = ctx.mock_prover(); ctx.close()
+    bad_g, bad_l = plan.check_constraints(advice.data_ptr(), n, stream)
+    assert bad_g == 0
+    assert bad_l <= 2 * 4                      # at most the PoW limbs of each proof
+    sel = np.unpackbits(np.frombuffer(plan.selectors(), dtype=np.uint8), bitorder="little")
+    gate_cells = np.nonzero(sel)[0]
+    a = advice.view(torch.int64)
+    for g in (gate_cells[5], gate_cells[len(gate_cells) // 2], gate_cells[-1]):
+        idx = (plan.num_cells + int(g) + 3) * 4          # proof 1, the gate's output cell, low limb
+        old = a[idx].item(); a[idx] = old ^ 1
+        assert plan.check_constraints(advice.data_ptr(), n, stream)[0] >= 1
+        a[idx] = old
+    assert plan.check_constraints(advice.data_ptr(), n, stream)[0] == 0
+    lk = plan.lookup_cells()
+    idx = int(lk[len(lk) // 3]) * 4 + 1                  # proof 0: a looked-up limb gets a high word
+    a[idx] = 1
+    assert plan.check_constraints(advice.data_ptr(), n, stream)[1] >= bad_l + 1
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(16, 28, 2, 0, 342848685 + 90444), (20, 28, 1, 0, 450331361 + 117724), (20, 84, 1, 1, 59708779 + 328424 + 1)],
+                         ids=["cfg2-gl", "cfg3-gl", "cfg5-bn254"])
+def test_full_size_streams_satisfy_all_gates_and_lookups(h2w, h2w_api, oracle, consts, cfg):
+    """BASELINE.json configs at full size where a cell-by-cell comparison with the oracle is too large for a unit test (cfg 2 / 3
+    with Goldilocks-Poseidon Merkle caps: 11 / 14.4 GB of advice per proof; cfg 5: 84 queries) -> the size-independent property:
+    every gate and every lookup of the stream holds on the device (the PoW limbs of a random proof aside), and the stream has
+    exactly the cell count of SURVEY §8d (verify_proof subtree + witness-load cells; BN254 mode + the one cached load_zero cell, App. A)."""
+    import torch
+    ko, kh = consts
+    d, q, rb, mode, cells = cfg
+    sh = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=mode)
+    osh = oracle.fibonacci_shape(d, q, rate_bits=rb, hash_mode=mode)
+    plan = h2w_api.Plan(sh, kh)
+    assert plan.num_cells == cells
+    p = oracle.synth_proof(osh, 0xF1B00002)
+    d_proofs = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64).cuda()
+    advice = torch.empty(plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.run(d_proofs.data_ptr(), 1, advice.data_ptr(), ws.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert plan.status(ws.data_ptr(), 1, stream) == [0]
+    bad_g, bad_l = plan.check_constraints(advice.data_ptr(), 1, stream)
+    assert bad_g == 0 and bad_l <= 4, (bad_g, bad_l)
+    assert int(plan.L.h2w_plan_num_gates(plan.p)) > plan.num_cells // 5
+    plan.close()
