@@ -557,7 +557,10 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
         if (!two_pass) {
             // PoseidonBN254 Merkle chain strands (4 lanes each) emit their permutations' cells themselves; extra y slot: query glue
             A.role_base = p->d.n_oracles + p->d.n_steps;
-            if (!(dbg_skip & 2)) hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(QUAD_BLOCK), 0, stream, A);
+            // LDS padding (dynamic, unused): 32 KB staging + pad caps the kernel at 4 wavefronts per CU, so the remaining LDS can hold
+            // blocks of another batch's expansion kernel instead of a fifth chain wavefront (env override for A/B)
+            static int pad = -1; if (pad < 0) { const char *e = getenv("H2W_QUAD_PAD_LDS"); pad = e ? atoi(e) : 0; }
+            if (!(dbg_skip & 2)) hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(QUAD_BLOCK), (size_t)pad, stream, A);
             H2W_HIP(hipEventRecord(p->ev[4], stream));
         } else {
             // A/B path (H2W_BN_UNITS=1): one lane per chain stores every permutation's input state as a unit, a second kernel

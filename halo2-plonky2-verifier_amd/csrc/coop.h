@@ -385,10 +385,29 @@ struct QuadSink {
                     const fr_t kc = bnk(0, BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r);
                     const fr_t ksx = bnk(0, BK_S + ix), ksxm = bnk(1, BK_S + ix), ksy = bnk(0, BK_S + iy), ksym = bnk(1, BK_S + iy);
                     need(52);
-                    exp5(l == 0 ? 0 : -64); add_const(l == 0 ? 12 : -64, kc);
+                    // Five wavefront-level Montgomery products per partial round instead of seven: the lanes that have no S-box do
+                    // their own work inside the S-box's instruction stream.
+                    //   A: lane 0  X = s0 R          | lanes 1-3  S_j * s_j          (their terms of the sparse row; s_j is not touched by the S-box)
+                    //   B: lane 0  x2 = s0 X         | lane 1     X2 = X X
+                    //   C: lane 0  x4 = x2 X2 ;  D: lane 0  x5 = x4 X ;  then s0' = x5 + c
+                    //   E: lane 0  S_0 * s0'         | lanes 1-3  S'_k * s0'         (column update)
+                    const fr_t A_ = fr_mont_mul(s, l == 0 ? r2 : ksxm, ninv);
+                    const fr_t Xb = shfl4(A_, 0);
+                    const fr_t B_ = fr_mont_mul(l == 0 ? s : Xb, Xb, ninv);
+                    const fr_t X2b = shfl4(B_, 1);
+                    const fr_t x4 = fr_mont_mul(B_, X2b, ninv), x5 = fr_mont_mul(x4, Xb, ninv);
+                    {   // lane 0's S-box cells [0,s,s,x2, 0,x2,x2,x4, 0,x4,s,x5] and +c [c][x5, c, 1, x5+c]
+                        const int q = l == 0 ? 0 : -64; const fr_t ns = fr_add(x5, kc);
+                        W64(q, 0); W(q + 1, s); W(q + 2, s); W(q + 3, B_);
+                        W64(q + 4, 0); W(q + 5, B_); W(q + 6, B_); W(q + 7, x4);
+                        W64(q + 8, 0); W(q + 9, x4); W(q + 10, s); W(q + 11, x5);
+                        W(q + 12, kc); W(q + 13, x5); W(q + 14, kc); W64(q + 15, 1); W(q + 16, ns);
+                        if (l == 0) s = ns;
+                    }
                     so += 17;
                     const fr_t s0 = shfl4(s, 0);
-                    const fr_t pr = fr_mont_mul(s, ksxm, ninv);                         // S[j] * s_j (lane 0: new s0)
+                    const fr_t E_ = fr_mont_mul(s0, l == 0 ? ksxm : ksym, ninv);
+                    const fr_t pr = l == 0 ? E_ : A_;                                    // S[j] * s_j
                     fr_t incl = pr, t = shfl4_up(incl, 1); if (l >= 1) incl = fr_add(incl, t);
                     t = shfl4_up(incl, 2); if (l >= 2) incl = fr_add(incl, t);
                     fr_t excl = shfl4_up(incl, 1); if (l == 0) excl = fr_zero();
@@ -397,7 +416,7 @@ struct QuadSink {
                     const fr_t ns0 = shfl4(incl, 3);
                     {
                         const int p = l > 0 ? 5 * lm : -64;
-                        const fr_t nv = fr_add(fr_mont_mul(s0, ksym, ninv), s);
+                        const fr_t nv = fr_add(E_, s);
                         W(p, ksy); W(p + 1, s); W(p + 2, ksy); W(p + 3, s0); W(p + 4, nv);
                         s = l > 0 ? nv : ns0;
                     }
