@@ -112,6 +112,10 @@ SYMBOLS = {
     "h2w_gl_mul_add": (C.c_int, [_vp, _av, _av, _av, _av]),
     "h2w_gl_div": (C.c_int, [_vp, _av, _av, _av]),
     "h2w_gl_inv": (C.c_int, [_vp, _av, _av]),
+    "h2w_gl_mul_sub": (C.c_int, [_vp, _av, _av, _av, _av]),
+    "h2w_gl_neg": (C.c_int, [_vp, _av, _av]),
+    "h2w_gl_square": (C.c_int, [_vp, _av, _av]),
+    "h2w_gl_exp_power_of_2": (C.c_int, [_vp, _av, C.c_size_t, _av]),
     "h2w_chip_ext_op": (C.c_int, [_vp, C.c_int, _av, _av, _av, _av]),
     "h2w_chip_gl_exp_from_bits_const_base": (C.c_int, [_vp, C.c_uint64, _av, C.c_size_t, _av]),
     "h2w_chip_gl_poseidon_permute": (C.c_int, [_vp, C.POINTER(PoseidonConsts), _av, _av]),

@@ -161,6 +161,18 @@ class GoldilocksChip:
     def inv(self, a):
         o = Assigned(); _ck(self.L.h2w_gl_inv(self.p, C.byref(a), C.byref(o)), "gl.inv"); return o
 
+    def mul_sub(self, a, b, c):
+        o = Assigned(); _ck(self.L.h2w_gl_mul_sub(self.p, C.byref(a), C.byref(b), C.byref(c), C.byref(o)), "gl.mul_sub"); return o
+
+    def neg(self, a):
+        o = Assigned(); _ck(self.L.h2w_gl_neg(self.p, C.byref(a), C.byref(o)), "gl.neg"); return o
+
+    def square(self, a):
+        o = Assigned(); _ck(self.L.h2w_gl_square(self.p, C.byref(a), C.byref(o)), "gl.square"); return o
+
+    def exp_power_of_2(self, a, power_log):
+        o = Assigned(); _ck(self.L.h2w_gl_exp_power_of_2(self.p, C.byref(a), power_log, C.byref(o)), "gl.exp_power_of_2"); return o
+
 
 class Plan:
     """Shape-compiled batched hot path (h2w_plan_* / h2w_fri_witness_batch)."""

@@ -338,6 +338,31 @@ int h2w_gl_div(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w
     glop(c, T_GLOP, b->value.l[0], res, 0, &prod);
     *out = rw; return 0;
 }
+// GoldilocksChip::mul_sub (base.rs:332-343): mul_no_reduce, sub_no_reduce (= prod + c*(p-1) with a NEG_ONE constant cell), reduce: 70 cells
+int h2w_gl_mul_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
+    GL_ARGS2("h2w_gl_mul_sub"); if (!fits64(cc->value)) return fail(c, "h2w_gl_mul_sub: operand is not a 64-bit Goldilocks wire");
+    {   // a*b + c*(p-1) must stay below 2^128 (the reference's reduce is only specified up to p*(p-1), base.rs:345); checked before any cell is emitted
+        const u128 ab = (u128)a->value.l[0] * b->value.l[0], cm = (u128)cc->value.l[0] * GL_NEG_ONE;
+        if (ab + cm < ab) return fail(c, "h2w_gl_mul_sub: a*b + c*(p-1) >= 2^128 (outside the range of GoldilocksChip::reduce, base.rs:345)");
+    }
+    h2w_assigned_t prod, neg_one, diff; const h2w_fr_t m1 = fr_from_u64(GL_NEG_ONE);
+    if (h2w_mul(c, a, b, &prod) != 0 || h2w_load_constant(c, &m1, &neg_one) != 0 || h2w_mul_add(c, cc, &neg_one, &prod, &diff) != 0) return -1;
+    return gl_reduce_impl(c, diff.value, out);
+}
+// GoldilocksChip::neg (base.rs:234-238): load_neg_one, mul
+int h2w_gl_neg(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) {
+    if (!check(c, "h2w_gl_neg")) return -1;
+    h2w_assigned_t neg_one; if (h2w_gl_load_constant(c, GL_NEG_ONE, &neg_one) != 0) return -1;
+    return h2w_gl_mul(c, a, &neg_one, out);
+}
+// GoldilocksChip::square (base.rs:401-404) and exp_power_of_2 (base.rs:433-445)
+int h2w_gl_square(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) { return h2w_gl_mul(c, a, a, out); }
+int h2w_gl_exp_power_of_2(h2w_ctx *c, const h2w_assigned_t *base, size_t power_log, h2w_assigned_t *out) {
+    if (!check(c, "h2w_gl_exp_power_of_2")) return -1;
+    h2w_assigned_t p = *base;
+    for (size_t i = 0; i < power_log; i++) { h2w_assigned_t q; if (h2w_gl_mul(c, &p, &p, &q) != 0) return -1; p = q; }
+    *out = p; return 0;
+}
 int h2w_gl_inv(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) {
     if (!check(c, "h2w_gl_inv")) return -1;
     h2w_assigned_t one; h2w_gl_load_constant(c, 1, &one);

@@ -75,7 +75,7 @@ template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXP
                 u128 b[B_COUNT];
                 b[B_A] = rc.a; b[B_B] = rc.b; b[B_C] = rc.c; b[B_D] = rc.d; b[B_V] = V;
                 b[B_X0] = X0; b[B_X0P] = X0 + two_rb - GL_P; b[B_X0PP] = X0 + two_rb;
-                b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb;
+                b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb; b[B_W] = X0 * (u128)GL_P + X1;
 #pragma unroll
                 for (int k = 0; k < B_COUNT; k++) { s_bases[tid][k].lo = (ull)b[k]; s_bases[tid][k].hi = (ull)(b[k] >> 64); }
             }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_w(ExpandArgs A) 
             u128 b[B_COUNT];
             b[B_A] = rc.a; b[B_B] = rc.b; b[B_C] = rc.c; b[B_D] = rc.d; b[B_V] = V;
             b[B_X0] = X0; b[B_X0P] = X0 + two_rb - GL_P; b[B_X0PP] = X0 + two_rb;
-            b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb;
+            b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb; b[B_W] = X0 * (u128)GL_P + X1;
 #pragma unroll
             for (int k = 0; k < B_COUNT; k++) { s_bases[wv][lane][k].lo = (ull)b[k]; s_bases[wv][lane][k].hi = (ull)(b[k] >> 64); }
         }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_r(ExpandArgs A) 
             u128 b[B_COUNT];
             b[B_A] = rc.a; b[B_B] = rc.b; b[B_C] = rc.c; b[B_D] = rc.d; b[B_V] = V;
             b[B_X0] = X0; b[B_X0P] = X0 + two_rb - GL_P; b[B_X0PP] = X0 + two_rb;
-            b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb;
+            b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb; b[B_W] = X0 * (u128)GL_P + X1;
 #pragma unroll
             for (int k = 0; k < B_COUNT; k++) { s_bases[wv][lane][k].lo = (ull)b[k]; s_bases[wv][lane][k].hi = (ull)(b[k] >> 64); }
         }

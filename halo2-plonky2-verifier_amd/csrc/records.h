@@ -23,7 +23,9 @@ HD void g_store_rec(rec_t *p, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
 }
 
 // base indices
-enum { B_A = 0, B_B, B_C, B_D, B_V, B_X0, B_X0P, B_X0PP, B_X1, B_X1P, B_X1PP, B_COUNT };
+enum { B_A = 0, B_B, B_C, B_D, B_V, B_X0, B_X0P, B_X0PP, B_X1, B_X1P, B_X1PP,
+       B_W,          // X0 * p + X1: what reduce's closing mul_add gate outputs (= V unless the hinted quotient wrapped mod p, i.e. V div p >= p)
+       B_COUNT };
 // base modes
 enum { M_GLOP = 0,   // V = A*B + C ; (X0, X1) = (V div p, V mod p)
        M_LOADW = 1,  // (X0, X1) = (A, B) ; V = A*B + C
@@ -116,7 +118,7 @@ struct TemplateTable {
         emit_loadw(s, B_X0, B_X0P, B_X0PP);      // quotient
         emit_loadw(s, B_X1, B_X1P, B_X1PP);      // remainder
         s.push_back(Ku(GL_P));                   // load_constant(ORDER)
-        s.push_back(slot_field(B_X1, 0, 128)); flag(s, 0, CF_GATE); s.push_back(slot_field(B_X0, 0, 128)); s.push_back(Ku(GL_P)); s.push_back(slot_field(B_V, 0, 128));
+        s.push_back(slot_field(B_X1, 0, 128)); flag(s, 0, CF_GATE); s.push_back(slot_field(B_X0, 0, 128)); s.push_back(Ku(GL_P)); s.push_back(slot_field(B_W, 0, 128));
     }
     int finish(int id, std::vector<uint32_t> &s, int mode) {
         if ((int)info.size() <= id) info.resize(id + 1, tmpl_info_t{0, 0, 0, 0});

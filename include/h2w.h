@@ -128,6 +128,10 @@ int h2w_gl_mul(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_
 int h2w_gl_mul_add(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *c, h2w_assigned_t *out); /* :319-329 */
 int h2w_gl_div(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out);     /* :371-393 (93); error if b == 0 (:379) */
 int h2w_gl_inv(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                              /* :395-399 (94) */
+int h2w_gl_mul_sub(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *c, h2w_assigned_t *out); /* :332-343 (70) */
+int h2w_gl_neg(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                              /* :234-238 (1 + 65) */
+int h2w_gl_square(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                           /* :401-404 (65) */
+int h2w_gl_exp_power_of_2(h2w_ctx *, const h2w_assigned_t *base, size_t power_log, h2w_assigned_t *out); /* :433-445 (65 * power_log) */
 
 /* ------------------------------------------------------------------ 2b. the reference's higher chips over the eager boundary
  * (host side above the C-ABI: csrc/chips.h + csrc/verifier.h instantiated on a backend that only calls the functions above).

@@ -62,6 +62,16 @@ def test_goldilocks_ops(h2w_api, oracle, lookup_bits):
             assert gq.int_value() == oq.v.to_int() and gq.offset == oq.cell
             gi, oi = pr.gl.inv(gb), L.orc_gl_inv(op, ob)
             assert gi.int_value() == oi.v.to_int()
+        if a * b + b * (P - 1) < 2**128:       # beyond that the reference's reduce is out of its supported range (base.rs:345 TODO); the ABI returns an error
+            gms, oms = pr.gl.mul_sub(ga, gb, gw), L.orc_gl_mul_sub(op, oa, ob, ow)
+            assert gms.int_value() == oms.v.to_int() == (a * b - b) % P and gms.offset == oms.cell
+            gsq, osq = pr.gl.exp_power_of_2(gms, 3), L.orc_gl_exp_power_of_2(op, oms, 3)
+            assert gsq.int_value() == osq.v.to_int() == pow((a * b - b) % P, 8, P) and gsq.offset == osq.cell
+        else:
+            with pytest.raises(h2w_api.H2WError):
+                pr.gl.mul_sub(ga, gb, gw)
+        gn, on_ = pr.gl.neg(ga), L.orc_gl_mul(op, oa, L.orc_gl_load_constant(op, P - 1))        # neg = load_neg_one, mul (base.rs:234-238)
+        assert gn.int_value() == on_.v.to_int() == (-a) % P and gn.offset == on_.cell
         # reduce of an unreduced native product / sum
         gp, opd = pr.nat.mul_add(ga, gb, gw), L.orc_mul_add(op, oa, ob, ow)
         gr, orr = pr.gl.reduce(gp), L.orc_gl_reduce(op, opd)
