@@ -79,6 +79,23 @@ def test_goldilocks_ops(h2w_api, oracle, lookup_bits):
     pr.check()
 
 
+@pytest.mark.parametrize("lookup_bits", [21, 13])
+def test_reduce_at_the_edges_of_its_range(h2w_api, oracle, lookup_bits):
+    """GoldilocksChip::reduce (base.rs:346-368) on 128-bit values around the points where its hint changes shape: the largest
+    mul_add value p(p-1)+(p-1), p^2 (quotient = p wraps to 0), 2^128-1 (quotient >= 2^64), multiples of p, tiny values.  The cells
+    follow the reference even where its constraint would fail (quotient reduced mod p)."""
+    pr = Pair(h2w_api, oracle, lookup_bits)
+    L, op = pr.L, pr.octx.p
+    for v in [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**64, P * (P - 1) + (P - 1), P * P - 1, P * P, P * P + 1, (P - 2) * 2**64, 2**127, 2**128 - 2**64, 2**128 - 1,
+              (2**64 + 2**32) * P - 1, (2**64 + 2**32) * P]:
+        if v >= 2**128:
+            continue
+        (g, o) = pr.const(v)
+        gr, orr = pr.gl.reduce(g), L.orc_gl_reduce(op, o)
+        assert gr.int_value() == orr.v.to_int() == v % P and gr.offset == orr.cell, hex(v)
+    pr.check()
+
+
 def test_native_ops(h2w_api, oracle):
     rnd = random.Random(11)
     pr = Pair(h2w_api, oracle)
