@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
-    if (threadIdx.x == 0) A.status[p] = be.status;
+    if (threadIdx.x == 0) A.status[p] = be.status ? be.status : sink.load_flag;
 }
 
 // Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot

@@ -76,16 +76,19 @@ struct CoopSink {
     __device__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
     __device__ bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
+    uint32_t load_flag = 0;      // set by coop_load_proof: some word is outside its field's canonical range (status 4)
     __device__ __noinline__ bool coop_load_proof(const ValCfg &cfg) {
+        bool bad = false;
         for (uint32_t i = lane; i < cfg.n_load_items; i += 64) {
             const uint64_t *ip = reinterpret_cast<const uint64_t *>(cfg.load_items + i);
             const uint64_t wk = g_load_u64(ip), irec = g_load_u64(ip + 1), icell = g_load_u64(ip + 2);
             const uint32_t word = (uint32_t)wk, kind = (uint32_t)(wk >> 32);
             const uint64_t *w = cfg.proof + word; const uint64_t w0 = g_load_u64(w);
-            if (kind <= 1) g_store_rec(recs + irec, w0, 0, 0, 0);
-            else if (kind == 2) g_store_rec(recs + irec, w0, g_load_u64(w + 1), g_load_u64(w + 2), g_load_u64(w + 3));
-            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); g_store_fr(out + icell, v); }
+            if (kind <= 1) { g_store_rec(recs + irec, w0, 0, 0, 0); bad |= w0 >= GL_P; }
+            else if (kind == 2) { const uint64_t w1 = g_load_u64(w + 1), w2 = g_load_u64(w + 2), w3 = g_load_u64(w + 3); g_store_rec(recs + irec, w0, w1, w2, w3); bad |= w0 >= GL_P || w1 >= GL_P || w2 >= GL_P || w3 >= GL_P; }
+            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); g_store_fr(out + icell, v); bad |= fr_geq_mod(v); }
         }
+        if (__any(bad)) load_flag = 4;
         nrec += cfg.load_nrec; cell_off += cfg.load_ncell;
         return true;
     }

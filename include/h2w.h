@@ -202,7 +202,11 @@ int h2w_layout_lookup_columns(h2w_plan *, const void *advice_dev, uint64_t proof
 int h2w_check_constraints(h2w_plan *, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs,
                           uint64_t bad[2], void *stream);
 
-/* Per-proof device status words (0 = ok; non-zero = reference would have panicked, e.g. inverse of zero) */
+/* Per-proof device status words.  0 = ok.  1 = GoldilocksChip::div by zero (reference asserts, base.rs:379), 2 = extension
+ * inverse of zero (extension.rs:327), 3 = challenger input buffer overflow, 4 = the proof holds a word outside its field's
+ * canonical range (a Goldilocks word >= p or a BN254 hash >= r: not representable by the reference's types; the cells are
+ * still produced — identical to the reference's arithmetic for Goldilocks words, unreduced for the hash).  The first
+ * condition met wins. */
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);

@@ -141,6 +141,38 @@ def test_shape_edge_cases(h2w, h2w_api, oracle, consts, mode):
     assert status == [0] and all(rc == 0 and n == nc and same for rc, err, n, same in outs)
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+def test_noncanonical_proof_words_are_flagged(h2w, h2w_api, oracle, consts, mode):
+    """Words the reference's types cannot hold (a Goldilocks word >= p, a BN254 hash >= r): status 4.  Goldilocks words still give
+    the oracle's cells (both sides compute on the raw 64-bit value); in-range proofs keep status 0."""
+    import random
+    import torch
+    ko, kh = consts
+    P = 2**64 - 2**32 + 1
+    sh = h2w.fibonacci_shape(6, 2, hash_mode=mode); osh = oracle.fibonacci_shape(6, 2, hash_mode=mode)
+    plan = h2w_api.Plan(sh, kh)
+    rnd = random.Random(3)
+    for trial in range(3):
+        pr = oracle.synth_proof(osh, 100 + trial)
+        if trial:                         # trial 0: untouched
+            for _ in range(10):
+                i = rnd.randrange(len(pr))
+                pr[i] = rnd.choice([P, P + 1, 2**64 - 1])
+        d_proofs = torch.frombuffer(bytearray(bytes(pr)), dtype=torch.int64).cuda()
+        advice = torch.zeros(plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(plan.workspace_bytes(1), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        plan.run(d_proofs.data_ptr(), 1, advice.data_ptr(), ws.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert plan.status(ws.data_ptr(), 1, st) == [4 if trial else 0]
+        if mode == 0 or trial == 0:
+            ctx = oracle.Ctx(21)
+            assert oracle.verify_stark(ctx, osh, ko, pr) == 0
+            assert ctx.advice_bytes() == advice.cpu().numpy().tobytes()
+            ctx.close()
+    plan.close()
+
+
 def test_device_status_where_reference_panics(h2w, h2w_api, oracle, consts):
     """GoldilocksChip::div asserts b != 0 (base.rs:379); ext inv of 0 likewise.  A proof crafted to hit it (subgroup_x - zeta
     = 0 cannot be forced without the challenger, so use scalar_div by a zero coset start: not reachable either) -> instead

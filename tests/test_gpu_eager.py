@@ -147,3 +147,57 @@ def test_native_ops(h2w_api, oracle):
         (g, o) = pr.wit(v)
         pr.nat.check_less_than_safe(g, bound); L.orc_check_less_than_safe(op, o, bound)
     pr.check()
+
+
+def test_native_ops_off_domain(h2w_api, oracle):
+    """Inputs the verifier never produces but the NativeChip API accepts (witness generation does not validate them; only the
+    prover would fail): non-boolean selectors and "bits", values larger than the range they are checked against, non-indicator
+    indicators.  The product either emits the reference's cells (oracle parity) or refuses loudly before emitting anything."""
+    rnd = random.Random(12)
+    pr = Pair(h2w_api, oracle)
+    L, op, O = pr.L, pr.octx.p, oracle
+    H2WError = h2w_api.H2WError
+
+    def both(gfn, ofn):
+        """run the op on both sides; if the product refuses, it must not have appended cells and the oracle side is skipped"""
+        n0 = pr.ctx.num_cells()
+        try:
+            g = gfn()
+        except H2WError:
+            assert pr.ctx.num_cells() == n0
+            return None
+        return g, ofn()
+
+    vals = [2, 3, R - 1, (1 << 64) + 5, rnd.randrange(R), rnd.randrange(1 << 128)]
+    for sel in vals:
+        (ga, oa), (gb, ob), (gs, os_) = pr.wit(rnd.randrange(R)), pr.wit(rnd.randrange(1 << 64)), pr.wit(sel)
+        r = both(lambda: pr.nat.select(ga, gb, gs), lambda: L.orc_select(op, oa, ob, os_))
+        if r: assert r[0].int_value() == r[1].v.to_int() and r[0].offset == r[1].cell
+    for n in (3, 8):
+        bits = [pr.wit(rnd.choice([0, 1, 2, 5, R - 1])) for _ in range(n)]
+        r = both(lambda: pr.nat.bits_to_num([g for g, _ in bits]), lambda: L.orc_bits_to_num(op, (O.AV * n)(*[o for _, o in bits]), n))
+        if r: assert r[0].int_value() == r[1].v.to_int() and r[0].offset == r[1].cell
+    for v, nb in [(1 << 70, 64), ((1 << 20) + 1, 8), (R - 1, 16)]:
+        (g, o) = pr.wit(v)
+        ob_ = (O.AV * nb)()
+        r = both(lambda: pr.nat.num_to_bits(g, nb), lambda: L.orc_num_to_bits(op, o, nb, ob_))
+        if r: assert [x.int_value() for x in r[0]] == [ob_[i].v.to_int() for i in range(nb)]
+    for v, nb in [(1 << 50, 48), ((1 << 64) - 1, 48), (rnd.randrange(1 << 128), 84), (rnd.randrange(R), 64), (R - 1, 21)]:
+        (g, o) = pr.wit(v)
+        both(lambda: pr.nat.range_check(g, nb), lambda: L.orc_range_check(op, o, nb))
+    for v, bound in [(P, P), (P + 5, P), ((1 << 64) - 1, P), (1 << 90, P), (1000, 5), (rnd.randrange(R), P)]:
+        (g, o) = pr.wit(v)
+        both(lambda: pr.nat.check_less_than_safe(g, bound), lambda: L.orc_check_less_than_safe(op, o, bound))
+    for n in (4,):
+        arr = [pr.wit(rnd.randrange(R)) for _ in range(n)]
+        ind = [pr.wit(rnd.choice([0, 1, 2, R - 1])) for _ in range(n)]
+        oout = (O.AV * 1)()
+        r = both(lambda: pr.nat.select_array_by_indicator([[g] for g, _ in arr], [g for g, _ in ind]),
+                 lambda: L.orc_select_array_by_indicator(op, (O.AV * n)(*[o for _, o in arr]), n, 1, (O.AV * n)(*[o for _, o in ind]), oout))
+        if r: assert r[0][0].int_value() == oout[0].v.to_int()
+    for v in [rnd.randrange(R), R - 1, 1 << 253]:
+        (g, o) = pr.wit(v)
+        ol_ = (O.AV * 5)()
+        r = both(lambda: pr.nat.decompose_le(g, 56, 5), lambda: L.orc_decompose_le(op, o, 56, 5, ol_))
+        if r: assert [x.int_value() for x in r[0]] == [ol_[i].v.to_int() for i in range(5)]
+    pr.check()
