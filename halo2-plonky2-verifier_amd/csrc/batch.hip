@@ -508,8 +508,10 @@ static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_c
     o_cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
     o_status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
     o_units = o; o += align_up((size_t)n * p->nunit * 4 * sizeof(fr_t), 256);
+    o += align_up((size_t)n * sizeof(uint32_t), 256);      // expansion kernel's per-proof tile counters (last region)
     total = o;
 }
+static size_t ws_ctr_offset(uint64_t n, size_t total) { return total - align_up((size_t)n * sizeof(uint32_t), 256); }
 uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
     if (!p) return 0;
     size_t a, b, c, d2, t; ws_layout(p, n_proofs, a, b, c, d2, t); return t;
@@ -579,6 +581,9 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
     ExpandArgs E;
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
     p->dt.fill(E); E.rb = p->tt.rb;
+    static int dyn_tiles = -1; if (dyn_tiles < 0) { const char *e = getenv("H2W_EXPAND_STATIC_TILES"); dyn_tiles = !(e && e[0] == '1'); }
+    E.tile_ctr = dyn_tiles ? (uint32_t *)(ws + ws_ctr_offset(n_proofs, total)) : nullptr;
+    if (E.tile_ctr) H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
     if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, p->ev[1], 0));    // value strands done -> expansion on the emit stream
     if (!(dbg_skip & 4)) launch_expand(E, n_proofs, gx, estream);

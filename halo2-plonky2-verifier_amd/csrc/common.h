@@ -24,6 +24,7 @@ struct ExpandArgs {
     const tmpl_info_t *info; uint32_t ntmpl;
     const fr_t *consts; uint32_t nconsts;
     int rb;
+    uint32_t *tile_ctr;        // [nproofs] zeroed work counters: tiles are handed out dynamically (null: static striding)
 };
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
 

@@ -43,7 +43,15 @@ template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXP
     const uint64_t ntiles = (A.nrec + TILE_RECS - 1) / TILE_RECS;
     const u128 two_rb = (u128)1 << A.rb;
 
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tiles differ in size (1 to 66 cells per record), so a static tile -> block assignment leaves a tail of straggling blocks;
+    // with a per-proof work counter every block takes the next tile when it is done (the fetch for the next tile is issued by an
+    // otherwise idle wavefront during the record phase and read after the tile's closing barrier).
+    __shared__ uint32_t s_next;
+    const bool dyn = A.tile_ctr != nullptr;
+    uint64_t tile = blockIdx.x;
+    if (dyn) { if (tid == 0) s_next = atomicAdd(&A.tile_ctr[proof], 1u); __syncthreads(); tile = s_next; __syncthreads(); }
+    for (; tile < ntiles;) {
+        if (dyn && tid == 64) s_next = atomicAdd(&A.tile_ctr[proof], 1u);
         const uint64_t r0 = tile * TILE_RECS;
         const int nr = (int)((A.nrec - r0) < TILE_RECS ? (A.nrec - r0) : TILE_RECS);
         if (tid < TILE_RECS) {
@@ -119,6 +127,8 @@ template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXP
             dst[0] = vlo; dst[1] = vhi;
         }
         __syncthreads();
+        tile = dyn ? (uint64_t)s_next : tile + gridDim.x;
+        if (dyn) __syncthreads();          // s_next is rewritten at the top of the next tile
     }
 }
 
