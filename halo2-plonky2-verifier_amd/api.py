@@ -240,6 +240,11 @@ class Plan:
         bp = (C.c_uint64 * max(len(break_points), 1))(*break_points)
         _ck(self.L.h2w_layout_columns(advice_ptr, self.num_cells, self.num_cells if proof_stride is None else proof_stride, n, bp, len(break_points), k, columns_ptr, stream), "h2w_layout_columns")
 
+    def run_columns(self, proofs_ptr, n, break_points, k, columns_ptr, workspace_ptr, stream=0):
+        """Batched hot path writing the FlexGate column layout directly (h2w_fri_witness_batch_columns)."""
+        bp = (C.c_uint64 * max(len(break_points), 1))(*break_points)
+        _ck(self.L.h2w_fri_witness_batch_columns(self.p, proofs_ptr, n, bp, len(break_points), k, columns_ptr, workspace_ptr, stream), "h2w_fri_witness_batch_columns")
+
     def num_lookup_columns(self, k, unusable_rows=9):
         n = C.c_uint64()
         _ck(self.L.h2w_layout_lookup_columns(self.p, None, 0, 0, k, unusable_rows, None, C.byref(n), None), "h2w_layout_lookup_columns")

@@ -20,9 +20,7 @@
 namespace h2w {
 
 typedef ValBackend<DevSink> DevB;
-typedef ChallengeBlock<DevB> DevCB;
-typedef ValBackend<CoopSink> CoopB;
-typedef ValBackend<QuadSink> QuadB;   // same wire types as DevB: ChallengeBlock layouts coincide
+typedef ChallengeBlock<DevB> DevCB;   // (the wire types of every backend coincide: one ChallengeBlock layout)
 
 static const void *g_const_owner = nullptr;
 
@@ -82,6 +80,7 @@ struct BatchArgs {
     int nproofs, role_base, dbg_skip_perm;
     fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
+    ColMap cm;      // column-major emission (starts == nullptr: flat advice)
 };
 
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
@@ -97,22 +96,24 @@ __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
 #define H2W_QUAD_WAVES 1
 #endif
 #define H2W_WAVES __attribute__((amdgpu_waves_per_eu(H2W_QUAD_WAVES, H2W_QUAD_WAVES)))
-__global__ __launch_bounds__(64) H2W_WAVES void k_prologue(BatchArgs A) {
+template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_prologue(BatchArgs A) {
+    typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.nproofs) return;
-    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells;
+    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.cc.init(A.cm);
     DevB be(sink, make_cfg(A, p), true);
     Verifier<DevB> V(be, A.shape, A.consts);
-    V.prologue(A.cbs[p]);
+    V.prologue(*reinterpret_cast<ChallengeBlock<DevB> *>(&A.cbs[p]));
     A.status[p] = be.status;
 }
 
 // one wavefront per proof: wave-uniform gadget code, Goldilocks Poseidon split over 12 lanes (coop.h)
-__global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
+template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
+    typedef CoopSinkT<COLS> CoopSink; typedef ValBackend<CoopSink> CoopB;
     __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
-    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm;
+    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm; sink.cc.init(A.cm);
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
@@ -120,14 +121,15 @@ __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
 }
 
 // Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot
-__global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
+template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
+    typedef CoopSinkT<COLS> CoopSink; typedef ValBackend<CoopSink> CoopB;
     __builtin_amdgcn_s_setprio(3);
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int idx = blockIdx.x, nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x;
+    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
@@ -142,22 +144,24 @@ __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
 }
 
 // PoseidonBN254 Merkle chain strands (hash_mode 1): four lanes per (proof, query, kind); blockIdx.y = kind slot
-__device__ void glue_lane(const BatchArgs &A, int idx) {   // FriChip::verify_query_round minus its Merkle proofs: one lane per (proof, query)
+template <bool COLS> __device__ void glue_lane(const BatchArgs &A, int idx) {
+    typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;   // FriChip::verify_query_round minus its Merkle proofs: one lane per (proof, query)
     const int nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq;
-    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells;
+    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
     DevB be(sink, make_cfg(A, p), true);
     Verifier<DevB> V(be, A.shape, A.consts);
-    V.query_round(q, A.cbs[p]);
+    V.query_round(q, *reinterpret_cast<const ChallengeBlock<DevB> *>(&A.cbs[p]));
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
-__global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_merkle_bn_quad(BatchArgs A) {
+template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_merkle_bn_quad(BatchArgs A) {
+    typedef QuadSinkT<COLS> QuadSink; typedef ValBackend<QuadSink> QuadB;
     __builtin_amdgcn_s_setprio(3);
     const int nq = A.shape.num_queries, total = A.nproofs * nq;
     if ((int)blockIdx.y == A.role_base) {               // last y slot: the query glue strands, one lane each
         const int gi = blockIdx.x * QUAD_BLOCK + threadIdx.x;
-        if (gi < total && !(A.dbg_skip_perm & 8)) glue_lane(A, gi);
+        if (gi < total && !(A.dbg_skip_perm & 8)) glue_lane<COLS>(A, gi);
         return;
     }
     stage_bn_consts(threadIdx.x, QUAD_BLOCK);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_merkle_bn_quad(BatchAr
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    QuadSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3;
+    QuadSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
     ValCfg mc = make_cfg(A, p); mc.split_bn = true;
     QuadB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
@@ -185,16 +189,17 @@ __global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_merkle_bn_quad(BatchAr
 }
 
 // blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
-__global__ __launch_bounds__(64) H2W_WAVES void k_strands(BatchArgs A) {
+template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_strands(BatchArgs A) {
+    typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
     __builtin_amdgcn_s_setprio(3);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = A.shape.num_queries;
     if (idx >= A.nproofs * nq) return;
     const int p = idx / nq, q = idx % nq, role = A.role_base + blockIdx.y, sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;   // initial oracles
-    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells;
+    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
-    const DevCB &cb = A.cbs[p];
+    const ChallengeBlock<DevB> &cb = *reinterpret_cast<const ChallengeBlock<DevB> *>(&A.cbs[p]);
     if (role == 0) {
         DevB be(sink, make_cfg(A, p), true);
         Verifier<DevB> V(be, A.shape, A.consts);
@@ -374,6 +379,7 @@ struct h2w_plan {
     BnConsts h_bn[2];
     h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
+    uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
     uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64;
@@ -493,6 +499,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->d_lookup_cells) (void)hipFree(p->d_lookup_cells);
     if (p->d_sel_bits) (void)hipFree(p->d_sel_bits);
+    if (p->d_col_tab) (void)hipFree(p->d_col_tab);
     if (p->ev_ready) (void)hipEventDestroy(p->t_done);
     if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->evr[r][i]);
     p->dt.free();
@@ -516,11 +523,51 @@ uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
     if (!p) return 0;
     size_t a, b, c, d2, t; ws_layout(p, n_proofs, a, b, c, d2, t); return t;
 }
-int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_);
+static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride);
 int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
-    return h2w_fri_witness_batch2(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_);
+    ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
+    return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_, flat, p ? p->ncells : 0);
 }
 int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_) {
+    ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
+    return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, emit_stream_, flat, p ? p->ncells : 0);
+}
+// column-major emission: boundary cells repeated in the previous column, unused rows zeroed
+__global__ void k_columns_fixup(ulonglong2 *cols, const uint64_t *lens, uint32_t ncols, uint32_t k) {
+    const uint64_t rows2 = (uint64_t)2 << k; const uint32_t p = blockIdx.z, c = blockIdx.y;
+    ulonglong2 *col = cols + ((uint64_t)p * ncols + c) * rows2; const uint64_t len2 = lens[c] * 2;
+    if (c + 1 < ncols && blockIdx.x == 0 && threadIdx.x < 2) col[len2 - 2 + threadIdx.x] = col[rows2 + threadIdx.x];       // (c, len-1) <- (c+1, 0)
+    for (uint64_t h = len2 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < rows2; h += (uint64_t)gridDim.x * blockDim.x) col[h] = make_ulonglong2(0, 0);
+}
+int h2w_fri_witness_batch_columns(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, const uint64_t *break_points, uint64_t n_bp, int k,
+                                  void *columns_dev, void *workspace_dev, void *stream_) {
+    if (!p || (!break_points && n_bp) || !columns_dev) { set_error("h2w_fri_witness_batch_columns: null argument"); return -1; }
+    if (k < 12 || k > 34 || n_bp + 1 > 4096) { set_error("h2w_fri_witness_batch_columns: k must be in [12, 34] and at most 4096 columns"); return -1; }
+    if (p->device < 0) { set_error("h2w_fri_witness_batch_columns: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
+    const uint64_t ncols = n_bp + 1; std::vector<uint64_t> h(2 * ncols); uint64_t start = 0;
+    for (uint64_t c = 0; c < ncols; c++) {
+        const uint64_t len = c < n_bp ? break_points[c] + 1 : p->ncells - start;
+        if (start + len > p->ncells || len > ((uint64_t)1 << k) || len < 2) { set_error("h2w_fri_witness_batch_columns: break points do not fit the stream"); return -1; }
+        h[c] = start; h[ncols + c] = len; start += len - (c < n_bp ? 1 : 0);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    if (h != p->h_col_tab || k != p->col_k) {      // (re)upload the column table; plans are single-threaded handles (include/h2w.h)
+        H2W_HIP(hipDeviceSynchronize());             // a previous call on another stream may still read the old table
+        if (p->d_col_tab) { (void)hipFree(p->d_col_tab); p->d_col_tab = nullptr; }
+        H2W_HIP(hipMalloc((void **)&p->d_col_tab, h.size() * sizeof(uint64_t)));
+        H2W_HIP(hipMemcpy(p->d_col_tab, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        p->h_col_tab = h; p->col_k = k;
+    }
+    ColMap cm; cm.starts = p->d_col_tab; cm.ncols = (uint32_t)ncols; cm.k = (uint32_t)k;
+    if (run_batch(p, proofs_dev, n_proofs, columns_dev, workspace_dev, stream_, stream_, cm, ncols << k) != 0) return -1;
+    if (n_proofs) {
+        if (n_proofs > 65535) { set_error("h2w_fri_witness_batch_columns: too many proofs per call"); return -1; }
+        hipLaunchKernelGGL(k_columns_fixup, dim3(64, (unsigned)ncols, (unsigned)n_proofs), dim3(256), 0, stream, (ulonglong2 *)columns_dev, p->d_col_tab + ncols, (uint32_t)ncols, (uint32_t)k);
+        H2W_HIP(hipGetLastError());
+    }
+    return 0;
+}
+static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride) {
     if (!p) { set_error("h2w_fri_witness_batch: null plan"); return -1; }
     if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
@@ -531,7 +578,7 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
     char *ws = (char *)workspace_dev;
     BatchArgs A;
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
-    A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = p->ncells;
+    A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
     A.bn_perm_cells = 4032; A.role_base = 0;
@@ -542,13 +589,18 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
     H2W_HIP(hipEventRecord(p->ev[0], stream));
     static int dbg_skip = -1;      // timing experiments only (H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion) — results are then garbage
     if (dbg_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); dbg_skip = e ? atoi(e) : 0; }
-    if (!(dbg_skip & 1)) hipLaunchKernelGGL(k_prologue_coop, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
+    if (!(dbg_skip & 1)) { if (cm.starts) hipLaunchKernelGGL(k_prologue_coop<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_coop<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); }
     H2W_HIP(hipEventRecord(p->ev[3], stream));
     const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
     // roles: 0 = query glue, then one role per merkle strand kind (initial oracles, fold steps)
     if (p->shape.hash_mode == 0) {   // Goldilocks-Poseidon Merkle: glue lanes + one cooperating wavefront per Merkle strand
-        hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
-        hipLaunchKernelGGL(k_merkle_gl_coop, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+        if (cm.starts) {
+            hipLaunchKernelGGL(k_strands<true>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+            hipLaunchKernelGGL(k_merkle_gl_coop<true>, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+        } else {
+            hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+            hipLaunchKernelGGL(k_merkle_gl_coop<false>, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+        }
     } else {
         if (g_const_owner != (const void *)p) {   // (re)load the constant-memory BN254 tables for this plan, ordered on `stream`
             H2W_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_bn), p->h_bn, sizeof(p->h_bn), 0, hipMemcpyHostToDevice, stream));
@@ -556,19 +608,21 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
         }
         static int two_pass = -1;
         if (two_pass < 0) { const char *e = getenv("H2W_BN_UNITS"); two_pass = e && e[0] == '1'; }
+        if (two_pass && cm.starts) { set_error("column-major emission is not available on the H2W_BN_UNITS=1 A/B path"); return -1; }
         if (!two_pass) {
             // PoseidonBN254 Merkle chain strands (4 lanes each) emit their permutations' cells themselves; extra y slot: query glue
             A.role_base = p->d.n_oracles + p->d.n_steps;
             // LDS padding (dynamic, unused): 32 KB staging + pad caps the kernel at 4 wavefronts per CU, so the remaining LDS can hold
             // blocks of another batch's expansion kernel instead of a fifth chain wavefront (env override for A/B)
             static int pad = -1; if (pad < 0) { const char *e = getenv("H2W_QUAD_PAD_LDS"); pad = e ? atoi(e) : 0; }
-            if (!(dbg_skip & 2)) hipLaunchKernelGGL(k_merkle_bn_quad, dim3((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, (unsigned)(p->d.n_oracles + p->d.n_steps + 1)), dim3(QUAD_BLOCK), (size_t)pad, stream, A);
+            const dim3 qgrid((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, (unsigned)(p->d.n_oracles + p->d.n_steps + 1));
+            if (!(dbg_skip & 2)) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_quad<true>, qgrid, dim3(QUAD_BLOCK), (size_t)pad, stream, A); else hipLaunchKernelGGL(k_merkle_bn_quad<false>, qgrid, dim3(QUAD_BLOCK), (size_t)pad, stream, A); }
             H2W_HIP(hipEventRecord(p->ev[4], stream));
         } else {
             // A/B path (H2W_BN_UNITS=1): one lane per chain stores every permutation's input state as a unit, a second kernel
             // (one lane per permutation) re-evaluates the units and emits their cells
             A.role_base = 0;
-            hipLaunchKernelGGL(k_strands, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
+            hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
             H2W_HIP(hipEventRecord(p->ev[4], stream));
             const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
             const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
@@ -579,7 +633,7 @@ int h2w_fri_witness_batch2(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_p
     H2W_HIP(hipEventRecord(p->ev[1], stream));
     if (p->fifo_emit && p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
     ExpandArgs E;
-    E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = p->ncells; E.pool = nullptr;
+    E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
     p->dt.fill(E); E.rb = p->tt.rb;
     static int dyn_tiles = -1; if (dyn_tiles < 0) { const char *e = getenv("H2W_EXPAND_STATIC_TILES"); dyn_tiles = !(e && e[0] == '1'); }
     E.tile_ctr = dyn_tiles ? (uint32_t *)(ws + ws_ctr_offset(n_proofs, total)) : nullptr;

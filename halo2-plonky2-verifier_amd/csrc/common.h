@@ -25,6 +25,7 @@ struct ExpandArgs {
     const fr_t *consts; uint32_t nconsts;
     int rb;
     uint32_t *tile_ctr;        // [nproofs] zeroed work counters: tiles are handed out dynamically (null: static striding)
+    ColMap cm;                 // column-major emission (starts == nullptr: flat)
 };
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
 

@@ -48,15 +48,15 @@ __device__ __forceinline__ uint64_t gl_add_c(uint64_t x, uint64_t y) {   // cano
 }
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) { return __shfl_up(v, d, 64); }
 
-struct CoopSink {
+template <bool COLS> struct CoopSinkT {
     static constexpr bool kCoop = true;
-    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; int dbg_skip_perm = 0;
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; int dbg_skip_perm = 0; ColPolicy<COLS> cc;
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (lane == 0) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
     bool lane_mode = false, lane_on = false;     // lane_mode: every enabled lane writes cells at its OWN offset (coop_decompose_hashes)
-    __device__ __forceinline__ void cell(const fr_t &v) { if (lane_mode ? lane_on : lane == 0) g_store_fr(out + cell_off, v); cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (lane_mode ? lane_on : lane == 0) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
     __device__ bool unit_writer() const { return lane == 0; }
@@ -86,7 +86,7 @@ struct CoopSink {
             const uint64_t *w = cfg.proof + word; const uint64_t w0 = g_load_u64(w);
             if (kind <= 1) { g_store_rec(recs + irec, w0, 0, 0, 0); bad |= w0 >= GL_P; }
             else if (kind == 2) { const uint64_t w1 = g_load_u64(w + 1), w2 = g_load_u64(w + 2), w3 = g_load_u64(w + 3); g_store_rec(recs + irec, w0, w1, w2, w3); bad |= w0 >= GL_P || w1 >= GL_P || w2 >= GL_P || w3 >= GL_P; }
-            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); g_store_fr(out + icell, v); bad |= fr_geq_mod(v); }
+            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); g_store_fr(out + cc.map(icell), v); bad |= fr_geq_mod(v); }
         }
         if (__any(bad)) load_flag = 4;
         nrec += cfg.load_nrec; cell_off += cfg.load_ncell;
@@ -208,6 +208,7 @@ struct CoopSink {
         nrec += GLP_RECS; cell_off += 2 * HALF_N_FULL_ROUNDS * full_cells + part_cells;
     }
 };
+typedef CoopSinkT<false> CoopSink;
 
 // ---------------------------------------------------------------------------------------------------------------
 // QuadSink: four adjacent lanes execute one BN254 Merkle chain strand quad-uniformly (lane 0 of the quad writes the
@@ -255,14 +256,14 @@ __device__ __forceinline__ void stage_bn_consts(int, int) {}
 __device__ __forceinline__ fr_t bnk(int which, int idx) { return c_bn[which].c[idx]; }   // c, s, m, p are contiguous: one flat index (address space stays constant memory)
 #endif
 
-struct QuadSink {
+template <bool COLS> struct QuadSinkT {
     static constexpr bool kCoop = false;
-    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4;
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4; ColPolicy<COLS> cc;
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (l4 == 0) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
-    __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) g_store_fr(out + cell_off, v); cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
     __device__ bool unit_writer() const { return l4 == 0; }
@@ -301,15 +302,11 @@ struct QuadSink {
     static __device__ __forceinline__ void stage(int off, const fr_t &v) {
         if (off >= 0) { sq16_t *q = reinterpret_cast<sq16_t *>(s_quad_stage) + ((threadIdx.x >> 2) * QST + off) * 2; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]}; }
     }
-    // (static, lane index by value: a member read after wave_sync's memory clobber is a FLAT load from the sink object, and a flat
-    // load waits for vmcnt(0), i.e. for every cell store still in flight)
-    static __device__ __forceinline__ void flush(fr_t *&base, int &n, const int l4) {
-#ifdef H2W_ABL_NOFLUSH2
-        if (n != 12345) { base += n; n = 0; return; }
-#endif
-        wave_sync();
-        const sq16_t *src = reinterpret_cast<const sq16_t *>(s_quad_stage) + (threadIdx.x >> 2) * QST * 2;
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(base);
+    // (static, lane index / cursor by value: a member read after wave_sync's memory clobber is a FLAT load from the sink object, and a
+    // flat load waits for vmcnt(0), i.e. for every cell store still in flight)
+    static __device__ __forceinline__ void flush_run(fr_t *dst_cells, int first, int n, const int l4) {      // staged cells [first, first + n) -> dst_cells[0..n)
+        const sq16_t *src = reinterpret_cast<const sq16_t *>(s_quad_stage) + ((threadIdx.x >> 2) * QST + first) * 2;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(dst_cells);
         const int np = 2 * n;                                        // 16-byte pieces; lane k of the quad takes pieces k, k+4, ...
 #pragma unroll
         for (int u = 0; u < QST / 2; u += 4) {                       // 4 LDS reads in flight, then their 4 stores
@@ -317,15 +314,24 @@ struct QuadSink {
 #pragma unroll
             for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) t[v] = src[pc]; }
 #pragma unroll
-#ifdef H2W_ABL_NOFLUSH
-            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np && t[v].x == 0x123456789abcull) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
-#else
             for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
-#endif
             if ((u + 4) * 4 >= np) break;
         }
+    }
+    // column-major layout: a region can straddle one column boundary (out of line: only this mode pays for it)
+    static __device__ __noinline__ void flush_cols(fr_t *out, ColPolicy<true> &cc, uint64_t cell0, int n, const int l4) {
+        const uint64_t a0 = cc.map(cell0);
+        const int n0 = (cc.hi - cell0 < (uint64_t)n) ? (int)(cc.hi - cell0) : n;
+        flush_run(out + a0, 0, n0, l4);
+        if (n0 < n) { const uint64_t a1 = cc.map(cell0 + (uint64_t)n0); flush_run(out + a1, n0, n - n0, l4); }
+    }
+    // flush the n staged cells to the advice cells [cell0, cell0 + n)
+    static __device__ __forceinline__ void flush(fr_t *out, ColPolicy<COLS> &cc, uint64_t &cell0, int &n, const int l4) {
         wave_sync();
-        base += n; n = 0;
+        if constexpr (!COLS) flush_run(out + cell0, 0, n, l4);
+        else flush_cols(out, cc, cell0, n, l4);
+        wave_sync();
+        cell0 += (uint64_t)n; n = 0;
     }
     // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself (hash/poseidon_bn254/permutation.rs:48-203):
     // lane i owns state element i and the cells of "its" ops (x^5 of element i, ark i, row i of the mix, term j of the
@@ -334,7 +340,8 @@ struct QuadSink {
     __device__ __noinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
         bool zc = zc_ref;                      // by value: a reference would be re-read with a flat load (vmcnt(0)) at every mix
         const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
-        fr_t *base = out + cell_off;          // advice position of the staging region's first cell
+        uint64_t base = cell_off;             // flat cell index of the staging region's first cell
+        fr_t *const outp = out;      // (by value: see flush)
         int so = 0;                           // cells staged (quad-uniform)
         fr_t s = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
 #ifdef H2W_ABL_NOSTORE
@@ -343,7 +350,7 @@ struct QuadSink {
         auto W = [&](int off, const fr_t &v) { stage(off < 0 ? -1 : so + off, v); };
 #endif
         auto W64 = [&](int off, uint64_t v) { W(off, fr_from_u64(v)); };
-        auto need = [&](int n) { if (so + n > QST) flush(base, so, l); };
+        auto need = [&](int n) { if (so + n > QST) flush(outp, cc, base, so, l); };
         // x^5: 12 cells at region offset p (p < 0: this lane has no S-box here and keeps its s)
         auto exp5 = [&](int p) {
             const fr_t X = fr_mont_mul(s, r2, ninv);
@@ -435,9 +442,9 @@ struct QuadSink {
             need(48); exp5(12 * l); so += 48;
             if (half == 0) { ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(1); } else mix(0);
         }
-        flush(base, so, l);
+        flush(outp, cc, base, so, l);
         for (int j = 0; j < 4; j++) st[j] = shfl4(s, j);
-        cell_off = (uint64_t)(base - out); zc_ref = zc;
+        cell_off = base; zc_ref = zc;
         return true;
     }
     static __device__ __forceinline__ fr_t shfl4_up(const fr_t &v, int d) {
@@ -473,5 +480,6 @@ struct QuadSink {
         for (int j = 0; j < 4; j++) st[j] = shfl4(o, j);
     }
 };
+typedef QuadSinkT<false> QuadSink;
 
 }  // namespace h2w

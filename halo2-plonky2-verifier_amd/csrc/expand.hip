@@ -21,7 +21,7 @@ struct __attribute__((aligned(16))) u128s { ull lo, hi; };
 // static MAX_* worst case would be 9 KB) — the expansion kernel shares its CUs with the strand kernels of other batches, whose
 // staging regions hold most of the LDS, and every 16 KB block that does not fit is four fewer wavefronts streaming.
 extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_tables[];
-template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_t(ExpandArgs A) {
+template <int ABLATE, int TILE_RECS, int NSTEP, bool COLS = false> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_t(ExpandArgs A) {
     u128s *s_consts = reinterpret_cast<u128s *>(s_dyn_tables);
     uint32_t *s_slots = reinterpret_cast<uint32_t *>(s_consts + A.nconsts * 2);
     __shared__ tmpl_info_t s_info[T_MAX];
@@ -47,11 +47,16 @@ template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXP
     // with a per-proof work counter every block takes the next tile when it is done (the fetch for the next tile is issued by an
     // otherwise idle wavefront during the record phase and read after the tile's closing barrier).
     __shared__ uint32_t s_next;
+    // column-major emission: a record's cells are contiguous and cross at most one column boundary (the records of a tile are NOT
+    // contiguous with each other: direct cells and PoseidonBN254 permutations sit between them): cell s of record i goes to
+    // s_coff[i] + s (+ s_dd[i] from cell s_split[i] on), with the column shift already folded into s_coff
+    __shared__ uint32_t s_split[COLS ? TILE_RECS : 1]; __shared__ ull s_dd[COLS ? TILE_RECS : 1];
     const bool dyn = A.tile_ctr != nullptr;
     uint64_t tile = blockIdx.x;
     if (dyn) { if (tid == 0) s_next = atomicAdd(&A.tile_ctr[proof], 1u); __syncthreads(); tile = s_next; __syncthreads(); }
     for (; tile < ntiles;) {
         if (dyn && tid == 64) s_next = atomicAdd(&A.tile_ctr[proof], 1u);
+
         const uint64_t r0 = tile * TILE_RECS;
         const int nr = (int)((A.nrec - r0) < TILE_RECS ? (A.nrec - r0) : TILE_RECS);
         if (tid < TILE_RECS) {
@@ -63,7 +68,17 @@ template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXP
                 const tmpl_info_t ti = s_info[t];
                 n = ti.ncells;
                 s_sbase[tid] = ti.slot_base;
-                s_coff[tid] = meta_off(m);
+                {
+                    ull coff = meta_off(m);
+                    if constexpr (COLS) {
+                        ColCursor cc; cc.init(A.cm); cc.locate(coff);
+                        const ull room = cc.hi - coff, d0 = cc.delta;               // cells of this record before the next column starts
+                        ull dd = 0; uint32_t split = 0xffffffffu;
+                        if (room < 4096) { split = (uint32_t)room; cc.locate(cc.hi); dd = cc.delta - d0; }
+                        s_split[tid] = split; s_dd[tid] = dd; coff += d0;
+                    }
+                    s_coff[tid] = coff;
+                }
                 s_lit[tid] = ~0ull;
                 if (t == T_LITERAL) { n = (uint32_t)rc.b; s_lit[tid] = rc.a; }
                 u128 V, X0, X1;
@@ -123,7 +138,9 @@ template <int ABLATE, int TILE_RECS, int NSTEP> __global__ __launch_bounds__(EXP
                     vlo.lo = (ull)v; vlo.hi = (ull)(v >> 64);
                 }
             }
-            u128s *dst = ABLATE == 0 ? (u128s *)(out + s_coff[i] + s) : (u128s *)(out + s_coff[0] + j);
+            ull cellidx = s_coff[i] + s;
+            if constexpr (COLS) { if (s >= s_split[i]) cellidx += s_dd[i]; }
+            u128s *dst = ABLATE == 0 ? (u128s *)(out + cellidx) : (u128s *)(out + s_coff[0] + j);
             dst[0] = vlo; dst[1] = vhi;
         }
         __syncthreads();
@@ -328,7 +345,8 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
     uint64_t gx = (uint64_t)grid_x; if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)nproofs);
     const size_t dyn = ((size_t)A.nconsts * 32 + (size_t)A.nslots * 4 + 15) & ~(size_t)15;      // expand_kernel_t's tables
-    if (expand_variant() == 2) hipLaunchKernelGGL(expand_kernel_r, grid, dim3(EXPAND_THREADS), 0, stream, A);
+    if (A.cm.starts) hipLaunchKernelGGL((expand_kernel_t<0, 32, 5, true>), grid, dim3(EXPAND_THREADS), dyn, stream, A);      // the A/B variants write flat only
+    else if (expand_variant() == 2) hipLaunchKernelGGL(expand_kernel_r, grid, dim3(EXPAND_THREADS), 0, stream, A);
     else if (expand_variant() == 1) hipLaunchKernelGGL(expand_kernel_w, grid, dim3(EXPAND_THREADS), 0, stream, A);
     else if (expand_variant() == 11) hipLaunchKernelGGL((expand_kernel_t<1, 32, 5>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
     else if (expand_variant() == 12) hipLaunchKernelGGL((expand_kernel_t<2, 32, 5>), grid, dim3(EXPAND_THREADS), dyn, stream, A);

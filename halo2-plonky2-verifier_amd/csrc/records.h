@@ -22,6 +22,28 @@ HD void g_store_rec(rec_t *p, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
     H2W_GSTORE64(q, a); H2W_GSTORE64(q + 1, b); H2W_GSTORE64(q + 2, c); H2W_GSTORE64(q + 3, d);
 }
 
+// Column-major emission (fused): the advice is written straight into the FlexGate column layout.  Column c holds the
+// flat cells [starts[c], starts[c+1]] (the boundary cell is shared: it is the last row of column c and row 0 of column c+1);
+// a cell i lives at (c << k) + (i - starts[c]) for the LAST column c with starts[c] <= i; a fix-up kernel repeats the boundary cells
+// in the previous column and zero-fills the unused rows.  starts == nullptr: flat layout.
+struct ColMap { const uint64_t *starts; uint32_t ncols, k; };
+struct ColCursor {
+    ColMap m; uint64_t lo, hi; uint64_t delta;      // cells in [lo, hi) map to cell + delta (mod 2^64)
+    HD void init(const ColMap &cm) { m = cm; lo = 0; hi = cm.starts ? 0 : ~0ull; delta = 0; }
+    HNI void locate(uint64_t cell) {      // rare (once per column a strand enters): kept out of line
+        uint32_t a = 0, b = m.ncols;                   // largest c with starts[c] <= cell
+        while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (g_load_u64(m.starts + mid) <= cell) a = mid; else b = mid; }
+        lo = g_load_u64(m.starts + a); hi = a + 1 < m.ncols ? g_load_u64(m.starts + a + 1) : ~0ull;
+        delta = ((uint64_t)a << m.k) - lo;
+    }
+    HD uint64_t map(uint64_t cell) { if (cell < lo || cell >= hi) locate(cell); return cell + delta; }
+};
+
+// compile-time switch of the sinks / kernels: the flat instantiation carries no cursor at all
+template <bool COLS> struct ColPolicy;
+template <> struct ColPolicy<false> { HD void init(const ColMap &) {} HD uint64_t map(uint64_t c) const { return c; } };
+template <> struct ColPolicy<true> : ColCursor {};
+
 // base indices
 enum { B_A = 0, B_B, B_C, B_D, B_V, B_X0, B_X0P, B_X0PP, B_X1, B_X1P, B_X1PP,
        B_W,          // X0 * p + X1: what reduce's closing mul_add gate outputs (= V unless the hinted quotient wrapped mod p, i.e. V div p >= p)

@@ -228,12 +228,12 @@ template <class Sink> struct ValBackend {
 };
 
 // device sink: records into this proof's record array, direct cells into this proof's advice range
-struct DevSink {
+template <bool COLS> struct DevSinkT {
     static constexpr bool kCoop = false;
     HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
-    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells;
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; ColPolicy<COLS> cc;
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }
-    HF void cell(const fr_t &v) { g_store_fr(out + cell_off, v); cell_off++; }
+    HF void cell(const fr_t &v) { g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     HF void gate() {}
     HF void lookup() {}
     HF void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
@@ -254,5 +254,6 @@ struct DevSink {
     HF void begin_lane_cells(uint64_t, bool) {}
     HF void end_lane_cells(uint64_t) {}
 };
+typedef DevSinkT<false> DevSink;
 
 }  // namespace h2w

@@ -192,6 +192,11 @@ int h2w_break_points(const uint8_t *selectors, uint64_t n_cells, int k, int unus
 /* flat advice (device) -> columns[n_proofs][n_bp + 1][2^k] (device, 32-byte canonical Fr, unassigned rows zero) */
 int h2w_layout_columns(const void *advice_dev, uint64_t n_cells, uint64_t proof_stride_cells, uint64_t n_proofs,
                        const uint64_t *break_points, uint64_t n_bp, int k, void *columns_dev, void *stream);
+/* The same result as h2w_fri_witness_batch + h2w_layout_columns without materialising the flat stream: every kernel writes its
+ * cells straight to columns_dev[n_proofs][n_bp + 1][2^k] (a piecewise-constant address shift per column; a small fix-up kernel repeats
+ * the boundary cells and zeroes the unused rows).  k >= 12.  Workspace as for h2w_fri_witness_batch. */
+int h2w_fri_witness_batch_columns(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, const uint64_t *break_points, uint64_t n_bp,
+                                  int k, void *columns_dev, void *workspace_dev, void *stream);
 /* lookup advice columns: out[n_proofs][*n_cols_out][2^k]; out_dev may be NULL to query *n_cols_out */
 int h2w_layout_lookup_columns(h2w_plan *, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs,
                               int k, int unusable_rows, void *out_dev, uint64_t *n_cols_out, void *stream);

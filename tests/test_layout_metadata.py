@@ -95,7 +95,17 @@ def test_column_layout_on_device(h2w, h2w_api, oracle, consts, mode):
         nl = plan.num_lookup_columns(k)
         lk = torch.full((((n * nl) << k) * 32,), 0xCD, dtype=torch.uint8, device="cuda")
         assert plan.layout_lookup_columns(advice.data_ptr(), n, k, lk.data_ptr(), stream=stream) == nl
+        cols2 = torch.full((((n * ncol) << k) * 32,), 0x5A, dtype=torch.uint8, device="cuda")          # fused: the kernels write the columns directly
+        ws2 = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        plan.run_columns(d_proofs.data_ptr(), n, bp, k, cols2.data_ptr(), ws2.data_ptr(), stream)
         torch.cuda.synchronize()
+        assert plan.status(ws2.data_ptr(), n, stream) == [0] * n
+        if not torch.equal(cols, cols2):
+            a = cols.cpu().numpy().view(np.uint64).reshape(-1, 4); b = cols2.cpu().numpy().view(np.uint64).reshape(-1, 4)
+            bad = np.nonzero((a != b).any(axis=1))[0]
+            rows = 1 << k
+            raise AssertionError(f"k={k}: fused column-major emission differs from flat + relayout in {len(bad)} cells; first (proof, col, row) = "
+                                 f"{[(int(i) // (ncol * rows), (int(i) // rows) % ncol, int(i) % rows) for i in bad[:8]]} bp={bp[:4]} got {b[bad[0]]} want {a[bad[0]]}")
         got, gotl = cols.cpu().numpy().tobytes(), lk.cpu().numpy().tobytes()
         for i, p in enumerate(proofs):
             ctx = oracle.Ctx(21, witness_gen_only=False)
