@@ -240,6 +240,10 @@ class Plan:
         bp = (C.c_uint64 * max(len(break_points), 1))(*break_points)
         _ck(self.L.h2w_layout_columns(advice_ptr, self.num_cells, self.num_cells if proof_stride is None else proof_stride, n, bp, len(break_points), k, columns_ptr, stream), "h2w_layout_columns")
 
+    def run_shard(self, proofs_ptr, n, advice_ptr, workspace_ptr, rank, world, stream=0):
+        """This rank's (proof, query) units of the batch (h2w_fri_witness_batch_shard)."""
+        _ck(self.L.h2w_fri_witness_batch_shard(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, rank, world), "h2w_fri_witness_batch_shard")
+
     def run_columns(self, proofs_ptr, n, break_points, k, columns_ptr, workspace_ptr, stream=0):
         """Batched hot path writing the FlexGate column layout directly (h2w_fri_witness_batch_columns)."""
         bp = (C.c_uint64 * max(len(break_points), 1))(*break_points)

@@ -81,7 +81,9 @@ struct BatchArgs {
     fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
     ColMap cm;      // column-major emission (starts == nullptr: flat advice)
+    int shard_rank, shard_world;      // (proof, query) units are dealt round-robin to shard_world ranks (1: everything)
 };
+__device__ __forceinline__ bool own_unit(const BatchArgs &A, int p, int q) { return A.shard_world <= 1 || (int)(((long long)p * A.shape.num_queries + q) % A.shard_world) == A.shard_rank; }
 
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
@@ -127,6 +129,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_coop(Batc
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int idx = blockIdx.x, nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
+    if (!own_unit(A, p, q)) return;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
@@ -148,6 +151,7 @@ template <bool COLS> __device__ void glue_lane(const BatchArgs &A, int idx) {
     typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;   // FriChip::verify_query_round minus its Merkle proofs: one lane per (proof, query)
     const int nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq;
+    if (!own_unit(A, p, q)) return;
     DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
     DevB be(sink, make_cfg(A, p), true);
@@ -170,6 +174,7 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_m
     int idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
     if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes): keeps shuffles in-quad valid
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
+    if (!own_unit(A, p, q)) return;                     // quad-uniform
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     QuadSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
@@ -196,6 +201,7 @@ template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_strands(B
     const int nq = A.shape.num_queries;
     if (idx >= A.nproofs * nq) return;
     const int p = idx / nq, q = idx % nq, role = A.role_base + blockIdx.y, sq = q == 0 ? 0 : 1;
+    if (!own_unit(A, p, q)) return;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;   // initial oracles
     DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
@@ -523,7 +529,7 @@ uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
     if (!p) return 0;
     size_t a, b, c, d2, t; ws_layout(p, n_proofs, a, b, c, d2, t); return t;
 }
-static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride);
+static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, int shard_rank = 0, int shard_world = 1);
 int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
     ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
     return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_, flat, p ? p->ncells : 0);
@@ -567,7 +573,14 @@ int h2w_fri_witness_batch_columns(h2w_plan *p, const uint64_t *proofs_dev, uint6
     }
     return 0;
 }
-static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride) {
+// (proof, query) sharding: this rank generates the prologue block of every proof and the query blocks of the units
+// (proof * num_queries + query) % world == rank, at their global offsets in advice_dev; the other query blocks are left untouched.
+int h2w_fri_witness_batch_shard(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("h2w_fri_witness_batch_shard: bad rank / world"); return -1; }
+    ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
+    return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_, flat, p ? p->ncells : 0, rank, world);
+}
+static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, int shard_rank, int shard_world) {
     if (!p) { set_error("h2w_fri_witness_batch: null plan"); return -1; }
     if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
@@ -578,7 +591,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     char *ws = (char *)workspace_dev;
     BatchArgs A;
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
-    A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
+    A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm; A.shard_rank = shard_rank; A.shard_world = shard_world;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
     A.bn_perm_cells = 4032; A.role_base = 0;
@@ -634,6 +647,9 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (p->fifo_emit && p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
     ExpandArgs E;
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
+    E.shard_rank = (uint32_t)shard_rank; E.shard_world = (uint32_t)shard_world; E.nq = (uint32_t)p->shape.num_queries;
+    E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
+    if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
     p->dt.fill(E); E.rb = p->tt.rb;
     static int dyn_tiles = -1; if (dyn_tiles < 0) { const char *e = getenv("H2W_EXPAND_STATIC_TILES"); dyn_tiles = !(e && e[0] == '1'); }
     E.tile_ctr = dyn_tiles ? (uint32_t *)(ws + ws_ctr_offset(n_proofs, total)) : nullptr;

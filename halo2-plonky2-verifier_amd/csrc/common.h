@@ -26,6 +26,8 @@ struct ExpandArgs {
     int rb;
     uint32_t *tile_ctr;        // [nproofs] zeroed work counters: tiles are handed out dynamically (null: static striding)
     ColMap cm;                 // column-major emission (starts == nullptr: flat)
+    // (proof, query) sharding: records of query blocks owned by another rank are skipped (shard_world <= 1: none)
+    uint64_t q_rec0_first, q_rec0_rest, q_nrec_rest; uint32_t nq, shard_rank, shard_world;
 };
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
 

@@ -61,7 +61,15 @@ template <int ABLATE, int TILE_RECS, int NSTEP, bool COLS = false> __global__ __
         const int nr = (int)((A.nrec - r0) < TILE_RECS ? (A.nrec - r0) : TILE_RECS);
         if (tid < TILE_RECS) {
             uint32_t n = 0;
-            if (tid < nr) {
+            bool mine = tid < nr;
+            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block is kept by every rank
+                const uint64_t r = r0 + tid;
+                if (r >= A.q_rec0_first) {
+                    const uint64_t q = r < A.q_rec0_rest ? 0 : 1 + (r - A.q_rec0_rest) / A.q_nrec_rest;
+                    mine = (proof * A.nq + q) % A.shard_world == A.shard_rank;
+                }
+            }
+            if (mine) {
                 const uint64_t m = A.meta[r0 + tid];
                 const rec_t rc = recs[r0 + tid];
                 const uint32_t t = meta_tmpl(m);

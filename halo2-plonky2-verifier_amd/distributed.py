@@ -25,3 +25,12 @@ def max_over_ranks(value, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return value
+
+
+def unit_owner(proof, query, num_queries, world):
+    """SURVEY §8e partitioning: unit = (proof, query), round-robin over the ranks (h2w_fri_witness_batch_shard)."""
+    return (proof * num_queries + query) % world
+
+
+def my_units(n_proofs, num_queries, rank, world):
+    return [(p, q) for p in range(n_proofs) for q in range(num_queries) if unit_owner(p, q, num_queries, world) == rank]

@@ -207,6 +207,13 @@ int h2w_layout_lookup_columns(h2w_plan *, const void *advice_dev, uint64_t proof
 int h2w_check_constraints(h2w_plan *, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs,
                           uint64_t bad[2], void *stream);
 
+/* (proof, query) sharding across the GPUs of a node (north star: "independent FRI queries and Merkle paths sharded across
+ * the 8 GPUs"): rank r of `world` generates, at their global offsets in its own advice_dev[n_proofs][num_cells], the prologue
+ * block of every proof (witness load, challenger, PoW, reduced openings: needed for the challenges anyway) and the query blocks
+ * of the units (proof * num_queries + query) % world == r; the other query blocks are not touched.  No collective on the data
+ * path: every rank needs the proofs (one broadcast) and nothing else.  The byte-wise union over the ranks is the full stream. */
+int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev,
+                                void *stream, int rank, int world);
 /* Per-proof device status words.  0 = ok.  1 = GoldilocksChip::div by zero (reference asserts, base.rs:379), 2 = extension
  * inverse of zero (extension.rs:327), 3 = challenger input buffer overflow, 4 = the proof holds a word outside its field's
  * canonical range (a Goldilocks word >= p or a BN254 hash >= r: not representable by the reference's types; the cells are

@@ -60,3 +60,16 @@ def test_shard_range_properties():
             assert rs[0][0] == 0 and rs[-1][1] == total
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def test_query_unit_partition_is_exact():
+    """SURVEY §8e partitioning used by h2w_fri_witness_batch_shard: (proof, query) units round-robin over the ranks — every unit
+    has exactly one owner, shares differ by at most one unit, for any world size (the device kernels use the same formula)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    D = importlib.import_module("halo2-plonky2-verifier_amd.distributed")
+    for n_proofs, nq, world in [(1, 84, 8), (256, 28, 8), (3, 5, 4), (7, 1, 2), (2, 28, 3), (5, 4, 1)]:
+        shares = [D.my_units(n_proofs, nq, r, world) for r in range(world)]
+        flat = [u for s_ in shares for u in s_]
+        assert sorted(flat) == [(p, q) for p in range(n_proofs) for q in range(nq)]
+        assert max(map(len, shares)) - min(map(len, shares)) <= 1
