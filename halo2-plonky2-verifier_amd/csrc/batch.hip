@@ -848,6 +848,21 @@ int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest
     H2W_HIP(hipGetLastError());
     return 0;
 }
+// canonical -> Montgomery form (halo2curves bn256::Fr in memory: v * 2^256 mod r, little-endian limbs), in place.  One Montgomery
+// product per cell with the constant 2^(256+261) mod r (the device product divides by 2^261).
+__global__ void k_to_montgomery(fr_t *cells, uint64_t n, fr_t kconst, uint64_t ninv) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        g_store_fr(cells + i, fr_mont_mul(g_load_fr(cells + i), kconst, ninv));
+}
+int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream_) {
+    if (!cells_dev) { set_error("h2w_advice_to_montgomery: null argument"); return -1; }
+    if (n_cells == 0) return 0;
+    static const FrParams P = fr_params_init();
+    static const fr_t K = [] { fr_t x = fr_from_u64(1); for (int i = 0; i < 256 + FR_MONT_BITS; i++) x = fr_add(x, x); return x; }();
+    hipLaunchKernelGGL(k_to_montgomery, dim3(4096), dim3(256), 0, (hipStream_t)stream_, (fr_t *)cells_dev, n_cells, K, P.ninv);
+    H2W_HIP(hipGetLastError());
+    return 0;
+}
 int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batches before the last one (ring of 64)
     if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing: no such batch"); return -1; }
     hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];

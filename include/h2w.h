@@ -222,6 +222,9 @@ int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
 /* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);
+/* Output format: the stream is canonical little-endian Fr (what Fr::from_repr / to_repr use).  For a consumer that copies cells into
+ * halo2curves' in-memory representation (Montgomery form, R = 2^256) this converts n_cells cells in place on the device. */
+int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the call's stream:
  * ms[0] = prologue strands, ms[1] = query + Merkle strands, ms[2] = BN254 permutation-unit emission,
  * ms[3] = expansion kernel, ms[4] = whole batch.

@@ -234,6 +234,34 @@ def importlib_distributed():
     return importlib.import_module("halo2-plonky2-verifier_amd.distributed")
 
 
+def test_montgomery_form_output(h2w, h2w_api, oracle, consts):
+    """h2w_advice_to_montgomery: every cell becomes v * 2^256 mod r (halo2curves' in-memory Fr); checked against Python integers
+    on the whole stream of a small proof, and the conversion is a bijection (distinct digests, status untouched)."""
+    import numpy as np
+    import torch
+    ko, kh = consts
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    sh = h2w.fibonacci_shape(5, 1, hash_mode=1); osh = oracle.fibonacci_shape(5, 1, hash_mode=1)
+    plan = h2w_api.Plan(sh, kh)
+    pr = oracle.synth_proof(osh, 77)
+    d_proofs = torch.frombuffer(bytearray(bytes(pr)), dtype=torch.int64).cuda()
+    advice = torch.zeros(plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(1), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    plan.run(d_proofs.data_ptr(), 1, advice.data_ptr(), ws.data_ptr(), st)
+    torch.cuda.synchronize()
+    canon = advice.cpu().numpy().tobytes()
+    assert h2w.lib().h2w_advice_to_montgomery(advice.data_ptr(), plan.num_cells, st) == 0
+    torch.cuda.synchronize()
+    mont = advice.cpu().numpy().tobytes()
+    rng = np.random.default_rng(1)
+    idx = np.concatenate([np.arange(0, 2000), rng.integers(0, plan.num_cells, 20000), np.arange(plan.num_cells - 2000, plan.num_cells)])
+    for i in idx:
+        v = int.from_bytes(canon[32 * i:32 * i + 32], "little")
+        assert int.from_bytes(mont[32 * i:32 * i + 32], "little") == (v << 256) % R, int(i)
+    plan.close()
+
+
 def test_device_status_where_reference_panics(h2w, h2w_api, oracle, consts):
     """GoldilocksChip::div asserts b != 0 (base.rs:379); ext inv of 0 likewise.  A proof crafted to hit it (subgroup_x - zeta
     = 0 cannot be forced without the challenger, so use scalar_div by a zero coset start: not reachable either) -> instead

@@ -22,6 +22,7 @@ def timed(f, n=5):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n
 ms_c = timed(lambda: plan.layout_columns(advice.data_ptr(), B, bp, k, cols.data_ptr(), st))
 ms_l = timed(lambda: plan.layout_lookup_columns(advice.data_ptr(), B, k, lk.data_ptr(), stream=st))
+ms_m = timed(lambda: plan.L.h2w_advice_to_montgomery(advice.data_ptr(), B * plan.num_cells, st))
 nlk = len(plan.lookup_cells())
 # fused: the generation kernels write the columns directly (h2w_fri_witness_batch_columns) vs flat generation + relayout
 proofs = torch.zeros(B * plan.proof_words, dtype=torch.int64, device="cuda")
@@ -31,4 +32,5 @@ ms_fused = timed(lambda: plan.run_columns(proofs.data_ptr(), B, bp, k, cols.data
 print(json.dumps({"workload": f"cfg3 bn254, {B} proofs, k={k}", "metadata_replay_s": round(t_meta, 2), "columns": ncol, "lookup_columns": nl, "lookups_per_proof": nlk,
                   "layout_columns_ms": round(ms_c, 3), "layout_columns_GBps": round(B * (plan.num_cells * 32 + (ncol << k) * 32) / ms_c / 1e6, 1),
                   "generate_flat_ms": round(ms_flat, 3), "generate_flat_plus_relayout_ms": round(ms_flat + ms_c, 3), "generate_columns_fused_ms": round(ms_fused, 3),
+                  "to_montgomery_ms": round(ms_m, 3), "to_montgomery_GBps": round(B * plan.num_cells * 64 / ms_m / 1e6, 1),
                   "layout_lookup_ms": round(ms_l, 3), "layout_lookup_GBps": round(B * (nlk * 32 + (nl << k) * 32) / ms_l / 1e6, 1)}))
