@@ -10,6 +10,9 @@ N>1 (launched by torch.distributed.run, one rank per GPU): rank 0 builds the pro
 over RCCL (the only collective: SURVEY §8e); every rank then generates the witness of its own shard of proofs —
 no data-path collective — so per-GPU work is fixed ("weak" scaling) and value = all ranks' cells / max-rank time.
 
+The synthetic inputs (proof words, Poseidon tables) are drawn here with numpy; the CPU oracle (oracle/) is imported by the
+`cpu_baseline` leg only (rank 0, N=1), never by the measured path.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -101,11 +104,14 @@ def main():
     d, q, rb, desc = CONFIGS[args.config]
     hash_mode = 1 if args.hash == "bn254" else 0
     shape = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=hash_mode, lookup_bits=args.lookup_bits)
-    # Poseidon constants are caller inputs; synthetic (seeded) here — the real tables live in plonky2 / plonky2x.
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle as O   # used for synthetic INPUTS (proof/constant generator) and the cpu_baseline leg only
-    ko = O.synth_consts(0xC0FFEE)
-    consts = h2w.PoseidonConsts.from_buffer_copy(bytes(ko))
+    # Poseidon constants are caller inputs; synthetic (seeded) here — the real tables live in plonky2 / plonky2x.  Every 64-bit word
+    # is drawn below 2^60, so Goldilocks entries are canonical (< p) and every 4-word group is a canonical Fr (< 2^252 < r).
+    # (The oracle is not involved in the product path: it is imported by the cpu_baseline leg only.)
+    import ctypes as C
+    import numpy as np
+    rng = np.random.default_rng(0xC0FFEE)
+    consts = h2w.PoseidonConsts()
+    np.frombuffer((C.c_uint8 * C.sizeof(consts)).from_address(C.addressof(consts)), dtype=np.uint64)[:] = rng.integers(0, 1 << 60, C.sizeof(consts) // 8, dtype=np.uint64)
     plan = api.Plan(shape, consts, local_rank)
 
     cell_bytes = plan.num_cells * 32
@@ -118,11 +124,9 @@ def main():
     # ---- inputs: rank 0 synthesises all proofs, one RCCL broadcast moves the proof block
     words = plan.proof_words
     host = torch.empty(total_proofs * words, dtype=torch.int64)
-    if rank == 0:
-        osh = O.fibonacci_shape(d, q, rate_bits=rb, hash_mode=hash_mode, lookup_bits=args.lookup_bits)
-        for i in range(total_proofs):
-            pr = O.synth_proof(osh, 0xF1B00000 + i)
-            host[i * words:(i + 1) * words] = torch.frombuffer(bytearray(bytes(pr)), dtype=torch.int64)
+    if rank == 0:      # uniform random proof words (witness generation does not branch on validity, SURVEY §8d variant (B)); < 2^60: see above
+        prng = np.random.default_rng(0xF1B00000)
+        host[:] = torch.from_numpy(prng.integers(0, 1 << 60, total_proofs * words, dtype=np.int64))
     if args.backend == "gloo":                      # rehearsal: broadcast on the host, then upload
         D.broadcast_proofs(host, src=0)
         all_proofs = host.to(dev)
