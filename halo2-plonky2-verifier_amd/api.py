@@ -50,6 +50,31 @@ class Context:
         self.L.h2w_context_dump(self.p, buf, n + 1)
         return {line.rsplit(" ", 1)[0]: int(line.rsplit(" ", 1)[1]) for line in buf.value.decode().splitlines()}
 
+    # keygen-side bookkeeping (contexts created with witness_gen_only=False): halo2-base Context's selector / copy manager / lookups
+    def _u64s(self, nfn, fn, per=1):
+        n = int(nfn(self.p))
+        buf = (C.c_uint64 * max(per * n, 1))()
+        _ck(fn(self.p, buf), fn.__name__ if hasattr(fn, "__name__") else "h2w_ctx_*")
+        return n, buf
+
+    def gate_cells(self):
+        n, b = self._u64s(self.L.h2w_ctx_num_gates, self.L.h2w_ctx_gate_cells)
+        return [int(b[i]) for i in range(n)]
+
+    def lookup_cells(self):
+        n, b = self._u64s(self.L.h2w_ctx_num_lookups, self.L.h2w_ctx_lookup_cells)
+        return [int(b[i]) for i in range(n)]
+
+    def equalities(self):
+        n, b = self._u64s(self.L.h2w_ctx_num_equalities, self.L.h2w_ctx_equalities, 2)
+        return [(int(b[2 * i]), int(b[2 * i + 1])) for i in range(n)]
+
+    def const_equalities(self):
+        n = int(self.L.h2w_ctx_num_const_equalities(self.p))
+        cells = (C.c_uint64 * max(n, 1))(); vals = (Fr * max(n, 1))()
+        _ck(self.L.h2w_ctx_const_equalities(self.p, cells, vals), "h2w_ctx_const_equalities")
+        return [(int(cells[i]), int.from_bytes(bytes(vals[i]), "little")) for i in range(n)]
+
     def advice_bytes(self, first=0, count=None):
         """Expands the pending records on the GPU and returns canonical-LE cells as bytes."""
         n = self.num_cells() if count is None else count

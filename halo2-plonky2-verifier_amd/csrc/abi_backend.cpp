@@ -47,6 +47,8 @@ struct AbiBackend {
         ck(h2w_mul_add(ctx, &A, &B, &C, &o)); return o;
     }
     Gl gl_reduce(const Big &v) { Gl o; ck(h2w_gl_reduce(ctx, &v, &o)); return o; }
+    void assert_equal(const Gl &a, const Gl &b) { ck(h2w_constrain_equal(ctx, &a, &b)); }
+    void assert_equal_fr(const Fr &a, const Fr &b) { ck(h2w_constrain_equal(ctx, &a, &b)); }
     // ---- NativeChip level
     Gl select(const Gl &a, const Gl &b, const Bool &sel) { Gl o; ck(h2w_select(ctx, &a, &b, &sel, &o)); return o; }
     void idx_to_indicator(const Gl &idx, int len, Bool *out) { ck(h2w_idx_to_indicator(ctx, &idx, (size_t)len, out)); }

@@ -98,7 +98,7 @@ template <class B> struct GoldilocksChip {
         uint64_t bv = be.gl_val(b), av = be.gl_val(a);
         if (bv == 0) { be.fail(1); bv = 1; }                 // reference: assert!(b != 0) (:379)
         Gl res = load_witness(gl_mul(av, gl_inv(bv)));
-        mul(b, res);                                         // product; assert_equal(a, product) adds no cells
+        Gl prod = mul(b, res); be.assert_equal(a, prod);      // assert_equal adds no cells (a copy constraint; keygen bookkeeping only)
         return res;
     }
     HF Gl inv(Gl a) { Gl one = load_one(); return div(one, a); }                                    // :395-399
@@ -160,7 +160,8 @@ template <class B> struct QuadExtChip {
         gle_t av = value(a);
         if (av.c[0] == 0 && av.c[1] == 0) { be.fail(2); av.c[0] = 1; }
         Ex i = load_witness(gle_inv(av));
-        mul(a, i); load_one();                                // product, one; assert_equal adds no cells
+        Ex pr = mul(a, i), one = load_one();                  // assert_equal(product, one): no cells
+        be.assert_equal(pr.e[0], one.e[0]); be.assert_equal(pr.e[1], one.e[1]);
         return i;
     }
     HF Ex div(const Ex &a, const Ex &b) { Ex bi = inv(b); return mul(a, bi); }        // :237-246
@@ -378,6 +379,9 @@ template <class B> struct HasherChip {
         } else { Fr col[MAX_CAP]; for (int i = 0; i < n; i++) col[i] = cap(i).f; h.f = be.fr_select_from_idx(col, n, idx); }
         return h;
     }
+    HF void assert_equal(const H &a, const H &b) {      // poseidon/hash.rs:148-159 ; poseidon_bn254/hash.rs:145-154
+        if (mode == 0) { for (int i = 0; i < 4; i++) be.assert_equal(a.e[i], b.e[i]); } else be.assert_equal_fr(a.f, b.f);
+    }
     HF int to_goldilocks_vec(const H &h, Gl *out) {            // poseidon/hash.rs:22-30 ; poseidon_bn254/hash.rs:29-44
         if (mode == 0) { for (int i = 0; i < 4; i++) out[i] = h.e[i]; return 4; }
         be.decompose_le_56_5(h.f, out); return 5;
@@ -400,7 +404,8 @@ template <class B> struct MerkleTreeChip {
             H right = hs.select(node, sib, bits[i]);
             node = hs.two_to_one(left, right);
         }
-        hs.select_from_idx(n_cap, cap, cap_index);   // root; hasher_chip.assert_equal(root, node) adds no cells
+        H root = hs.select_from_idx(n_cap, cap, cap_index);
+        hs.assert_equal(root, node);                 // no cells
     }
 };
 

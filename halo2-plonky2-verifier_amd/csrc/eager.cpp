@@ -13,6 +13,7 @@
 #include <cstdio>
 #include "records.h"
 #include "common.h"
+#include "keygen.h"
 
 namespace h2w {
 
@@ -31,6 +32,7 @@ struct h2w_ctx {
     uint64_t ncells = 0;
     bool zero_set = false; uint64_t zero_off = 0;
     int err = 0;
+    MetaRecorder mr; bool keygen = false;       // witness_gen_only == 0: selectors / equalities / lookups (keygen.h)
     std::vector<fr_t> inv_pos, inv_neg;
     // ContextTree (util/context_tree.rs:11-123): scoped cell counters
     struct Node { int parent; std::string name; uint64_t cells; std::vector<int> children; };
@@ -152,11 +154,16 @@ void t_check_less_than_safe(h2w_ctx *c, const Av &a, uint64_t b) {
     t_range_check(c, mk(c, d, first), rb);
 }
 
+typedef MetaRecorder MR;
+inline int64_t off(const h2w_assigned_t *a) { return a && a->has_cell ? (int64_t)a->offset : -1; }
+// keygen bookkeeping must stay in step with the cell stream
+inline int kg_done(h2w_ctx *c, const char *fn);
 bool check(h2w_ctx *c, const char *fn) {
     if (!c) { set_error(std::string(fn) + ": null context"); return false; }
     return true;
 }
 int fail(h2w_ctx *c, const std::string &msg) { if (c) c->err = 1; set_error(msg); return -1; }
+inline int kg_done(h2w_ctx *c, const char *fn) { if (c->keygen && c->mr.row != c->ncells) return fail(c, std::string(fn) + ": internal: keygen bookkeeping out of step with the cell stream"); return 0; }
 
 }  // namespace
 
@@ -171,6 +178,7 @@ h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id) {
     h2w_ctx *c = new h2w_ctx(lookup_bits);
     c->L = lookup_bits; c->witness_gen_only = witness_gen_only; c->device = device_id; c->id = g_next_ctx_id++;
     c->P = fr_params_init();
+    c->keygen = witness_gen_only == 0; c->mr.L = lookup_bits;
     return c;
 }
 void h2w_ctx_free(h2w_ctx *c) {
@@ -185,88 +193,99 @@ void h2w_ctx_free(h2w_ctx *c) {
 uint64_t h2w_num_cells(const h2w_ctx *c) { return c ? c->ncells : 0; }
 int h2w_ctx_error(const h2w_ctx *c) { return c ? c->err : 1; }
 
-int h2w_load_constant(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_constant")) return -1; cell(c, *v); *out = mk(c, *v, c->ncells - 1); return 0; }
-int h2w_load_witness(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_witness")) return -1; cell(c, *v); *out = mk(c, *v, c->ncells - 1); return 0; }
+int h2w_load_constant(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_constant")) return -1; if (c->keygen) c->mr.load_constant(*v); cell(c, *v); *out = mk(c, *v, c->ncells - 1); return kg_done(c, "h2w_load_constant"); }
+int h2w_load_witness(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_witness")) return -1; if (c->keygen) c->mr.load_witness(); cell(c, *v); *out = mk(c, *v, c->ncells - 1); return kg_done(c, "h2w_load_witness"); }
 int h2w_load_zero(h2w_ctx *c, h2w_assigned_t *out) {
     if (!check(c, "h2w_load_zero")) return -1;
-    if (!c->zero_set) { cell(c, fr_zero()); c->zero_set = true; c->zero_off = c->ncells - 1; }
+    if (!c->zero_set) { if (c->keygen) c->mr.load_constant(fr_zero()); cell(c, fr_zero()); c->zero_set = true; c->zero_off = c->ncells - 1; }
     *out = mk(c, fr_zero(), c->zero_off); return 0;
 }
 int h2w_load_constants(h2w_ctx *c, const h2w_fr_t *v, size_t n, h2w_assigned_t *out) {
     if (!check(c, "h2w_load_constants")) return -1;
-    for (size_t i = 0; i < n; i++) { cell(c, v[i]); out[i] = mk(c, v[i], c->ncells - 1); }
-    return 0;
+    for (size_t i = 0; i < n; i++) { if (c->keygen) c->mr.load_constant(v[i]); cell(c, v[i]); out[i] = mk(c, v[i], c->ncells - 1); }
+    return kg_done(c, "h2w_load_constants");
 }
 int h2w_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     if (!check(c, "h2w_add")) return -1;
-    *out = t_gate(c, a->value, b->value, fr_from_u64(1)); return 0;      // [a, b, 1, a+b]
+    if (c->keygen) c->mr.add(MR::EX(off(a)), MR::EX(off(b)));
+    *out = t_gate(c, a->value, b->value, fr_from_u64(1)); return kg_done(c, "h2w_add");      // [a, b, 1, a+b]
 }
 int h2w_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     if (!check(c, "h2w_mul")) return -1;
-    *out = t_gate(c, fr_zero(), a->value, b->value); return 0;          // [0, a, b, a*b]
+    if (c->keygen) c->mr.mul(MR::EX(off(a)), MR::EX(off(b)));
+    *out = t_gate(c, fr_zero(), a->value, b->value); return kg_done(c, "h2w_mul");          // [0, a, b, a*b]
 }
 int h2w_mul_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
     if (!check(c, "h2w_mul_add")) return -1;
-    *out = t_gate(c, cc->value, a->value, b->value); return 0;          // [c, a, b, a*b+c]
+    if (c->keygen) c->mr.mul_add(MR::EX(off(a)), MR::EX(off(b)), MR::EX(off(cc)));
+    *out = t_gate(c, cc->value, a->value, b->value); return kg_done(c, "h2w_mul_add");          // [c, a, b, a*b+c]
 }
 int h2w_select(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *sel, h2w_assigned_t *out) {
     if (!check(c, "h2w_select")) return -1;
-    *out = t_select(c, a->value, b->value, sel->value); return 0;
+    if (c->keygen) c->mr.select(MR::EX(off(a)), MR::EX(off(b)), MR::EX(off(sel)));
+    *out = t_select(c, a->value, b->value, sel->value); return kg_done(c, "h2w_select");
 }
 int h2w_idx_to_indicator(h2w_ctx *c, const h2w_assigned_t *idx, size_t len, h2w_assigned_t *out) {
     if (!check(c, "h2w_idx_to_indicator")) return -1;
-    t_idx_to_indicator(c, idx->value, len, out); return 0;
+    if (c->keygen) { std::vector<int64_t> o(len); c->mr.idx_to_indicator(off(idx), len, o.data()); }
+    t_idx_to_indicator(c, idx->value, len, out); return kg_done(c, "h2w_idx_to_indicator");
 }
 int h2w_select_from_idx(h2w_ctx *c, const h2w_assigned_t *arr, size_t n, const h2w_assigned_t *idx, h2w_assigned_t *out) {
     if (!check(c, "h2w_select_from_idx")) return -1;
     std::vector<Av> ind(n);
+    if (c->keygen) { std::vector<int64_t> o(n), ao(n); c->mr.idx_to_indicator(off(idx), n, o.data()); for (size_t i = 0; i < n; i++) ao[i] = off(arr + i); c->mr.select_by_indicator(ao.data(), 1, o.data(), n); }
     t_idx_to_indicator(c, idx->value, n, ind.data());
-    *out = t_select_by_indicator(c, arr, 1, ind.data(), n); return 0;
+    *out = t_select_by_indicator(c, arr, 1, ind.data(), n); return kg_done(c, "h2w_select_from_idx");
 }
 int h2w_select_array_by_indicator(h2w_ctx *c, const h2w_assigned_t *arr2d, size_t len, size_t w, const h2w_assigned_t *ind, h2w_assigned_t *out) {
     if (!check(c, "h2w_select_array_by_indicator")) return -1;
+    if (c->keygen) { std::vector<int64_t> ao(len * w), io(len); for (size_t i = 0; i < len * w; i++) ao[i] = off(arr2d + i); for (size_t i = 0; i < len; i++) io[i] = off(ind + i); for (size_t j = 0; j < w; j++) c->mr.select_by_indicator(ao.data() + j, w, io.data(), len); }
     for (size_t j = 0; j < w; j++) out[j] = t_select_by_indicator(c, arr2d + j, w, ind, len);
-    return 0;
+    return kg_done(c, "h2w_select_array_by_indicator");
 }
 int h2w_num_to_bits(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits, h2w_assigned_t *out) {
     if (!check(c, "h2w_num_to_bits")) return -1;
     if (range_bits == 0 || range_bits > 253) return fail(c, "h2w_num_to_bits: range_bits out of range");
     std::vector<fr_t> bits(range_bits), bases(range_bits);
     for (size_t i = 0; i < range_bits; i++) { bits[i] = fr_from_u64(fr_bits(a->value, (int)i, 1)); bases[i] = fr_pow2((int)i); }
+    if (c->keygen) { std::vector<int64_t> o(range_bits); c->mr.num_to_bits(off(a), range_bits, o.data()); }
     uint64_t row = c->ncells;
     t_inner_product(c, bits.data(), bases.data(), range_bits);
     out[0] = mk(c, bits[0], row);
     for (size_t i = 1; i < range_bits; i++) out[i] = mk(c, bits[i], row + 1 + 3 * (i - 1));
     for (size_t i = 0; i < range_bits; i++) t_assert_bit(c, bits[i]);
-    return 0;
+    return kg_done(c, "h2w_num_to_bits");
 }
 int h2w_bits_to_num(h2w_ctx *c, const h2w_assigned_t *bits, size_t n, h2w_assigned_t *out) {
     if (!check(c, "h2w_bits_to_num")) return -1;
     std::vector<fr_t> a(n), b(n);
     for (size_t i = 0; i < n; i++) { a[i] = bits[i].value; b[i] = fr_pow2((int)i); }
-    *out = t_inner_product(c, a.data(), b.data(), n); return 0;
+    if (c->keygen) { std::vector<int64_t> o(n); for (size_t i = 0; i < n; i++) o[i] = off(bits + i); c->mr.bits_or_limbs_to_num(o.data(), n, 1); }
+    *out = t_inner_product(c, a.data(), b.data(), n); return kg_done(c, "h2w_bits_to_num");
 }
 int h2w_decompose_le(h2w_ctx *c, const h2w_assigned_t *num, size_t limb_bits, size_t num_limbs, h2w_assigned_t *out) {
     if (!check(c, "h2w_decompose_le")) return -1;
     if (limb_bits == 0 || limb_bits > 64) return fail(c, "h2w_decompose_le: limb_bits out of range");
     std::vector<fr_t> limbs(num_limbs), bases(num_limbs);
     for (size_t i = 0; i < num_limbs; i++) { limbs[i] = fr_from_u64(fr_bits(num->value, (int)(i * limb_bits), (int)limb_bits)); bases[i] = fr_pow2((int)(i * limb_bits)); }
+    if (c->keygen) { std::vector<int64_t> o(num_limbs); c->mr.decompose_le(off(num), limb_bits, num_limbs, o.data()); }
     uint64_t row = c->ncells;
     t_inner_product(c, limbs.data(), bases.data(), num_limbs);
     out[0] = mk(c, limbs[0], row);
     for (size_t i = 0; i + 1 < num_limbs; i++) out[i + 1] = mk(c, limbs[i + 1], row + 1 + 3 * i);
     for (size_t i = 0; i < num_limbs; i++) t_range_check(c, out[i], limb_bits);
-    return 0;
+    return kg_done(c, "h2w_decompose_le");
 }
 int h2w_limbs_to_num(h2w_ctx *c, const h2w_assigned_t *limbs, size_t n, size_t limb_bits, h2w_assigned_t *out) {
     if (!check(c, "h2w_limbs_to_num")) return -1;
     std::vector<fr_t> a(n), b(n);
     for (size_t i = 0; i < n; i++) { a[i] = limbs[i].value; b[i] = fr_pow2((int)(i * limb_bits)); }
-    *out = t_inner_product(c, a.data(), b.data(), n); return 0;
+    if (c->keygen) { std::vector<int64_t> o(n); for (size_t i = 0; i < n; i++) o[i] = off(limbs + i); c->mr.bits_or_limbs_to_num(o.data(), n, (int)limb_bits); }
+    *out = t_inner_product(c, a.data(), b.data(), n); return kg_done(c, "h2w_limbs_to_num");
 }
-int h2w_check_less_than_safe(h2w_ctx *c, const h2w_assigned_t *a, uint64_t b) { if (!check(c, "h2w_check_less_than_safe")) return -1; t_check_less_than_safe(c, *a, b); return 0; }
-int h2w_range_check(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits) { if (!check(c, "h2w_range_check")) return -1; t_range_check(c, *a, range_bits); return 0; }
-int h2w_constrain_equal(h2w_ctx *c, const h2w_assigned_t *, const h2w_assigned_t *) { return check(c, "h2w_constrain_equal") ? 0 : -1; }
+int h2w_check_less_than_safe(h2w_ctx *c, const h2w_assigned_t *a, uint64_t b) { if (!check(c, "h2w_check_less_than_safe")) return -1; if (c->keygen) c->mr.check_less_than_safe(off(a), b); t_check_less_than_safe(c, *a, b); return kg_done(c, "h2w_check_less_than_safe"); }
+int h2w_range_check(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits) { if (!check(c, "h2w_range_check")) return -1; if (c->keygen) c->mr.range_check(off(a), range_bits); t_range_check(c, *a, range_bits); return kg_done(c, "h2w_range_check"); }
+int h2w_constrain_equal(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b) { if (!check(c, "h2w_constrain_equal")) return -1; if (c->keygen) c->mr.equal(off(a), off(b)); return 0; }
 
 // ---------------------------------------------------------------- ContextWrapper::{push_context, pop_context} (util/context_wrapper.rs:28-34)
 int h2w_push_context(h2w_ctx *c, const char *name) {
@@ -299,8 +318,9 @@ static inline bool gl_canon(const fr_t &v) { return fits64(v) && v.l[0] < GL_P; 
 int h2w_gl_load_constant(h2w_ctx *c, uint64_t a, h2w_assigned_t *out) { fr_t v = fr_from_u64(a); return h2w_load_constant(c, &v, out); }
 int h2w_gl_load_witness(h2w_ctx *c, uint64_t a, h2w_assigned_t *out) {
     if (!check(c, "h2w_gl_load_witness")) return -1;
+    if (c->keygen) c->mr.gl_load_witness();
     uint64_t off = c->ncells; rec(c, T_LOADW, a, 0, 0, 0);
-    *out = mk(c, fr_from_u64(a), off); return 0;
+    *out = mk(c, fr_from_u64(a), off); return kg_done(c, "h2w_gl_load_witness");
 }
 // record for the 61-cell reduce tail of an arbitrary (< 2^128) value; returns remainder wire
 static int gl_reduce_impl(h2w_ctx *c, const fr_t &v, h2w_assigned_t *out) {
@@ -312,7 +332,7 @@ static int gl_reduce_impl(h2w_ctx *c, const fr_t &v, h2w_assigned_t *out) {
     *out = mk(c, fr_from_u64(r), off + (uint64_t)nl);    // remainder = second load_witness cell
     return 0;
 }
-int h2w_gl_reduce(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) { if (!check(c, "h2w_gl_reduce")) return -1; return gl_reduce_impl(c, a->value, out); }
+int h2w_gl_reduce(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) { if (!check(c, "h2w_gl_reduce")) return -1; if (c->keygen && !(a->value.l[2] | a->value.l[3])) c->mr.gl_reduce(off(a)); if (gl_reduce_impl(c, a->value, out) != 0) return -1; return kg_done(c, "h2w_gl_reduce"); }
 static int glop(h2w_ctx *c, int t, uint64_t A, uint64_t B, uint64_t C, h2w_assigned_t *out) {
     uint64_t r = gl_reduce128((u128)A * B + C);
     uint64_t off = c->ncells; rec(c, t, A, B, C, 0);
@@ -321,12 +341,17 @@ static int glop(h2w_ctx *c, int t, uint64_t A, uint64_t B, uint64_t C, h2w_assig
     return 0;
 }
 #define GL_ARGS2(fn) if (!check(c, fn)) return -1; if (!fits64(a->value) || !fits64(b->value)) return fail(c, std::string(fn) + ": operand is not a 64-bit Goldilocks wire")
-int h2w_gl_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_add"); return glop(c, T_GLOP, b->value.l[0], 1, a->value.l[0], out); }
-int h2w_gl_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_mul"); return glop(c, T_GLOP, a->value.l[0], b->value.l[0], 0, out); }
-int h2w_gl_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_sub"); return glop(c, T_KB_GLOP, b->value.l[0], GL_NEG_ONE, a->value.l[0], out); }
+int h2w_gl_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_add"); if (c->keygen) c->mr.gl_reduce(c->mr.add(MR::EX(off(a)), MR::EX(off(b)))); glop(c, T_GLOP, b->value.l[0], 1, a->value.l[0], out); return kg_done(c, "h2w_gl_add"); }
+int h2w_gl_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_mul"); if (c->keygen) c->mr.gl_reduce(c->mr.mul(MR::EX(off(a)), MR::EX(off(b)))); glop(c, T_GLOP, a->value.l[0], b->value.l[0], 0, out); return kg_done(c, "h2w_gl_mul"); }
+int h2w_gl_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
+    GL_ARGS2("h2w_gl_sub");
+    if (c->keygen) { const int64_t m1 = c->mr.load_constant(fr_from_u64(GL_NEG_ONE)); c->mr.gl_reduce(c->mr.mul_add(MR::EX(off(b)), MR::EX(m1), MR::EX(off(a)))); }
+    glop(c, T_KB_GLOP, b->value.l[0], GL_NEG_ONE, a->value.l[0], out); return kg_done(c, "h2w_gl_sub");
+}
 int h2w_gl_mul_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
     GL_ARGS2("h2w_gl_mul_add"); if (!fits64(cc->value)) return fail(c, "h2w_gl_mul_add: operand is not a 64-bit Goldilocks wire");
-    return glop(c, T_GLOP, a->value.l[0], b->value.l[0], cc->value.l[0], out);
+    if (c->keygen) c->mr.gl_reduce(c->mr.mul_add(MR::EX(off(a)), MR::EX(off(b)), MR::EX(off(cc))));
+    glop(c, T_GLOP, a->value.l[0], b->value.l[0], cc->value.l[0], out); return kg_done(c, "h2w_gl_mul_add");
 }
 int h2w_gl_div(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     GL_ARGS2("h2w_gl_div");
@@ -335,8 +360,9 @@ int h2w_gl_div(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w
     uint64_t res = gl_mul(a->value.l[0], gl_inv(b->value.l[0]));
     h2w_assigned_t rw, prod;
     h2w_gl_load_witness(c, res, &rw);
+    if (c->keygen) { const int64_t pr = c->mr.gl_reduce(c->mr.mul(MR::EX(off(b)), MR::EX(off(&rw)))); c->mr.equal(off(a), pr); }      // gl.assert_equal(a, b * res)
     glop(c, T_GLOP, b->value.l[0], res, 0, &prod);
-    *out = rw; return 0;
+    *out = rw; return kg_done(c, "h2w_gl_div");
 }
 // GoldilocksChip::mul_sub (base.rs:332-343): mul_no_reduce, sub_no_reduce (= prod + c*(p-1) with a NEG_ONE constant cell), reduce: 70 cells
 int h2w_gl_mul_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
@@ -347,7 +373,9 @@ int h2w_gl_mul_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b,
     }
     h2w_assigned_t prod, neg_one, diff; const h2w_fr_t m1 = fr_from_u64(GL_NEG_ONE);
     if (h2w_mul(c, a, b, &prod) != 0 || h2w_load_constant(c, &m1, &neg_one) != 0 || h2w_mul_add(c, cc, &neg_one, &prod, &diff) != 0) return -1;
-    return gl_reduce_impl(c, diff.value, out);
+    if (c->keygen) c->mr.gl_reduce(off(&diff));
+    if (gl_reduce_impl(c, diff.value, out) != 0) return -1;
+    return kg_done(c, "h2w_gl_mul_sub");
 }
 // GoldilocksChip::neg (base.rs:234-238): load_neg_one, mul
 int h2w_gl_neg(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) {
@@ -367,6 +395,20 @@ int h2w_gl_inv(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) {
     if (!check(c, "h2w_gl_inv")) return -1;
     h2w_assigned_t one; h2w_gl_load_constant(c, 1, &one);
     return h2w_gl_div(c, &one, a, out);
+}
+
+// ---------------------------------------------------------------- keygen-side metadata of the eager context (witness_gen_only == 0)
+static int kg_check(h2w_ctx *c, const char *fn) { if (!check(c, fn)) return -1; if (!c->keygen) return fail(c, std::string(fn) + ": the context was created with witness_gen_only != 0"); return 0; }
+uint64_t h2w_ctx_num_gates(h2w_ctx *c) { return c && c->keygen ? c->mr.sel.size() : 0; }
+uint64_t h2w_ctx_num_lookups(h2w_ctx *c) { return c && c->keygen ? c->mr.lookups.size() : 0; }
+uint64_t h2w_ctx_num_equalities(h2w_ctx *c) { return c && c->keygen ? c->mr.eq.size() / 2 : 0; }
+uint64_t h2w_ctx_num_const_equalities(h2w_ctx *c) { return c && c->keygen ? c->mr.ceq_cell.size() : 0; }
+int h2w_ctx_gate_cells(h2w_ctx *c, uint64_t *cells) { if (kg_check(c, "h2w_ctx_gate_cells") != 0 || !cells) return -1; memcpy(cells, c->mr.sel.data(), c->mr.sel.size() * 8); return 0; }
+int h2w_ctx_lookup_cells(h2w_ctx *c, uint64_t *cells) { if (kg_check(c, "h2w_ctx_lookup_cells") != 0 || !cells) return -1; memcpy(cells, c->mr.lookups.data(), c->mr.lookups.size() * 8); return 0; }
+int h2w_ctx_equalities(h2w_ctx *c, uint64_t *pairs) { if (kg_check(c, "h2w_ctx_equalities") != 0 || !pairs) return -1; memcpy(pairs, c->mr.eq.data(), c->mr.eq.size() * 8); return 0; }
+int h2w_ctx_const_equalities(h2w_ctx *c, uint64_t *cells, h2w_fr_t *values) {
+    if (kg_check(c, "h2w_ctx_const_equalities") != 0 || !cells || !values) return -1;
+    memcpy(cells, c->mr.ceq_cell.data(), c->mr.ceq_cell.size() * 8); memcpy(values, c->mr.ceq_val.data(), c->mr.ceq_val.size() * sizeof(fr_t)); return 0;
 }
 
 // ---------------------------------------------------------------- advice hand-off: GPU expansion

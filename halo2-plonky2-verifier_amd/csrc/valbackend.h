@@ -59,6 +59,8 @@ template <class Sink> struct ValBackend {
     HF void cell64(uint64_t v) { sink.cell(fr_from_u64(v)); }
     // keygen markers for the NEXT direct cell (no-ops on the device sinks; the shape compiler's PlanSink turns them into the
     // selector / lookup bitmaps of SURVEY §8f): G = a vertical gate starts there, LK = the cell is registered for the range lookup
+    HF void assert_equal(Gl, Gl) {}                  // copy constraints are not part of the advice stream
+    HF void assert_equal_fr(const Fr &, const Fr &) {}
     HF void G() { sink.gate(); }
     HF void LK() { sink.lookup(); }
 

@@ -238,7 +238,8 @@ template <class B> struct Verifier {
             Ex evals[MAX_ARITY]; for (int j = 0; j < ne; j++) evals[j] = proof_ext(ew + 2ull * j);
             Bool *coset_index_bits = x_index_bits + ab; const int ncb = nb - ab;
             Gl within = gl.bits_to_num(x_index_bits, ab);
-            ext.select_from_idx(evals, ne, within);                         // new_eval; assert_equal(new_eval, old_eval): no cells
+            Ex new_eval = ext.select_from_idx(evals, ne, within);
+            be.assert_equal(new_eval.e[0], old_eval.e[0]); be.assert_equal(new_eval.e[1], old_eval.e[1]);       // no cells
             old_eval = compute_evaluation(subgroup_x, x_index_bits, ab, evals, cb.fri_betas[i]);
             merkle_call(q, 3 + i, coset_index_bits, ncb, cap_index);
             subgroup_x = gl.exp_power_of_2(subgroup_x, ab);
@@ -246,7 +247,8 @@ template <class B> struct Verifier {
         }
         {   // eval_scalar (:324-335)
             Ex point = ext.load_base(subgroup_x);
-            ext.reduce_with_powers(d.final_poly_len, [&](int i) { return proof_ext(pl.final_poly + 2ull * i); }, point);
+            Ex eval = ext.reduce_with_powers(d.final_poly_len, [&](int i) { return proof_ext(pl.final_poly + 2ull * i); }, point);
+            be.assert_equal(eval.e[0], old_eval.e[0]); be.assert_equal(eval.e[1], old_eval.e[1]);               // no cells
         }
     }
     // bits / cap_index of query q's merkle strand `kind`, recomputed from the challenge value (device merkle lanes)

@@ -175,6 +175,14 @@ int h2w_fri_witness_batch(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_pro
  * waits for it).  Lets a caller give the latency-bound value strands and the streaming kernel differently CU-masked streams. */
 int h2w_fri_witness_batch2(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs,
                            void *advice_dev, void *workspace_dev, void *stream, void *emit_stream);
+/* ---- keygen-side bookkeeping of an eager context created with witness_gen_only == 0 (halo2-base Context when
+ * witness_gen_only is false; semantics [R]): gate cells (selector on), range-lookup registrations (in order),
+ * copy constraints (advice_equalities: pairs of cell offsets) and constant equalities (cell, constant). */
+uint64_t h2w_ctx_num_gates(h2w_ctx *);           int h2w_ctx_gate_cells(h2w_ctx *, uint64_t *cells);
+uint64_t h2w_ctx_num_lookups(h2w_ctx *);         int h2w_ctx_lookup_cells(h2w_ctx *, uint64_t *cells);
+uint64_t h2w_ctx_num_equalities(h2w_ctx *);      int h2w_ctx_equalities(h2w_ctx *, uint64_t *pairs /* 2 per equality */);
+uint64_t h2w_ctx_num_const_equalities(h2w_ctx *); int h2w_ctx_const_equalities(h2w_ctx *, uint64_t *cells, h2w_fr_t *values);
+
 /* ---- the consumer-side format of the advice stream -------------------------------------------
  * The cell stream of a shape is static, so its keygen metadata is too.  Restates (halo2-lib `community-edition`, not in
  * /root/reference; semantics [R]): Context::selector (one bit per cell: a vertical gate starts there),

@@ -1187,6 +1187,10 @@ void orc_selector_bitmap(const octx_t *c, uint8_t *out) {
     memset(out, 0, (c->n + 7) / 8);
     for (size_t i = 0; i < c->n && i < c->selcap; i++) if (c->selector[i]) out[i / 8] |= (uint8_t)(1u << (i & 7));
 }
+uint64_t orc_num_equalities(const octx_t *c) { return c->neq; }
+void orc_equalities(const octx_t *c, uint64_t *pairs) { for (size_t i = 0; i < c->neq; i++) { pairs[2 * i] = (uint64_t)c->eq[i].a; pairs[2 * i + 1] = (uint64_t)c->eq[i].b; } }
+uint64_t orc_num_const_equalities(const octx_t *c) { return c->nceq; }
+void orc_const_equalities(const octx_t *c, uint64_t *cells, ofr_t *values) { for (size_t i = 0; i < c->nceq; i++) { cells[i] = (uint64_t)c->ceq[i].cell; values[i] = c->ceq[i].c; } }
 uint64_t orc_num_lookups(const octx_t *c) { return c->nlookup; }
 void orc_lookup_cells(const octx_t *c, uint64_t *out) { for (size_t i = 0; i < c->nlookup; i++) out[i] = (uint64_t)c->lookup[i].cell; }
 uint64_t orc_break_points(const octx_t *c, int k, int unusable_rows, uint64_t *out, uint64_t cap) {

@@ -84,6 +84,10 @@ size_t orc_scope_dump(const octx_t *, char *buf, size_t cap);
 /* --- keygen metadata + FlexGate column layout (needs witness_gen_only = 0); halo2-lib semantics [R], see oracle.c --- */
 uint64_t orc_num_gates(const octx_t *);
 void orc_selector_bitmap(const octx_t *, uint8_t *out /* (num_cells + 7) / 8 */);
+uint64_t orc_num_equalities(const octx_t *);
+void orc_equalities(const octx_t *, uint64_t *pairs /* 2 per equality: copy constraints incl. chip-level assert_equal */);
+uint64_t orc_num_const_equalities(const octx_t *);
+void orc_const_equalities(const octx_t *, uint64_t *cells, ofr_t *values);
 uint64_t orc_num_lookups(const octx_t *);
 void orc_lookup_cells(const octx_t *, uint64_t *out);
 uint64_t orc_break_points(const octx_t *, int k, int unusable_rows, uint64_t *out, uint64_t cap);

@@ -99,6 +99,10 @@ def lib():
     L.orc_synth_proof.argtypes = [C.POINTER(Shape), C.c_uint64, C.POINTER(C.c_uint64)]
     L.orc_num_gates.restype = C.c_uint64; L.orc_num_gates.argtypes = [vp]
     L.orc_selector_bitmap.argtypes = [vp, vp]
+    L.orc_num_equalities.restype = C.c_uint64; L.orc_num_equalities.argtypes = [vp]
+    L.orc_equalities.argtypes = [vp, vp]
+    L.orc_num_const_equalities.restype = C.c_uint64; L.orc_num_const_equalities.argtypes = [vp]
+    L.orc_const_equalities.argtypes = [vp, vp, vp]
     L.orc_num_lookups.restype = C.c_uint64; L.orc_num_lookups.argtypes = [vp]
     L.orc_lookup_cells.argtypes = [vp, vp]
     L.orc_break_points.restype = C.c_uint64; L.orc_break_points.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
@@ -202,6 +206,23 @@ class Ctx:
         buf = (C.c_uint64 * max(n, 1))()
         self.L.orc_lookup_cells(self.p, buf)
         return list(buf[:n])
+
+    def equalities(self):
+        n = int(self.L.orc_num_equalities(self.p))
+        buf = (C.c_uint64 * max(2 * n, 1))()
+        self.L.orc_equalities(self.p, buf)
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+    def const_equalities(self):
+        n = int(self.L.orc_num_const_equalities(self.p))
+        cells = (C.c_uint64 * max(n, 1))(); vals = (Fr * max(n, 1))()
+        self.L.orc_const_equalities(self.p, cells, vals)
+        return [(int(cells[i]), vals[i].to_int()) for i in range(n)]
+
+    def gate_cells(self):
+        import numpy as np
+        sel = np.unpackbits(np.frombuffer(self.selectors(), dtype=np.uint8), bitorder="little")
+        return [int(i) for i in np.nonzero(sel)[0]]
 
     def break_points(self, k, unusable_rows=9):
         n = int(self.L.orc_break_points(self.p, k, unusable_rows, None, 0))
