@@ -149,6 +149,7 @@ SYMBOLS = {
     "h2w_ctx_num_lookups": (C.c_uint64, [_vp]), "h2w_ctx_lookup_cells": (C.c_int, [_vp, _vp]),
     "h2w_ctx_num_equalities": (C.c_uint64, [_vp]), "h2w_ctx_equalities": (C.c_int, [_vp, _vp]),
     "h2w_ctx_num_const_equalities": (C.c_uint64, [_vp]), "h2w_ctx_const_equalities": (C.c_int, [_vp, _vp, _vp]),
+    "h2w_check_equalities": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, _vp]),
     "h2w_plan_status": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint32), _vp]),
     "h2w_advice_digest": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "h2w_plan_last_timing": (C.c_int, [_vp, C.POINTER(C.c_float)]),

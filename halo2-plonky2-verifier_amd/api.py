@@ -290,6 +290,20 @@ class Plan:
         _ck(self.L.h2w_check_constraints(self.p, advice_ptr, self.num_cells if proof_stride is None else proof_stride, n, bad, stream), "h2w_check_constraints")
         return int(bad[0]), int(bad[1])
 
+    def check_equalities(self, advice_ptr, n, equalities, const_equalities, stream=0, proof_stride=None):
+        """(violated copy constraints, violated constant equalities) over n advice streams; lists from Context.equalities() /
+        Context.const_equalities() of an eager keygen context of the same shape."""
+        npairs, nconst = len(equalities), len(const_equalities)
+        pairs = (C.c_uint64 * max(2 * npairs, 1))(*[x for ab in equalities for x in ab])
+        cc = (C.c_uint64 * max(nconst, 1))(*[c for c, _ in const_equalities])
+        cv = (Fr * max(nconst, 1))()
+        for i, (_, v) in enumerate(const_equalities):
+            for j in range(4):
+                cv[i].l[j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        bad = (C.c_uint64 * 2)()
+        _ck(self.L.h2w_check_equalities(advice_ptr, self.num_cells, self.num_cells if proof_stride is None else proof_stride, n, pairs, npairs, cc, cv, nconst, bad, stream), "h2w_check_equalities")
+        return int(bad[0]), int(bad[1])
+
     def timing(self, back=0):
         """(prologue ms, strands ms, BN254-unit ms, expansion-kernel ms, total ms) of the batch call `back` calls before
         the last, from HIP events recorded on the call's stream."""

@@ -832,6 +832,40 @@ int h2w_check_constraints(h2w_plan *p, const void *advice_dev, uint64_t proof_st
     bad_out[0] = h[0]; bad_out[1] = h[1];
     return 0;
 }
+// copy constraints and constant equalities over device advice streams (the rest of the restated MockProver): the lists are static
+// per shape and come from an eager keygen context (h2w_ctx_equalities / h2w_ctx_const_equalities)
+__global__ void k_check_equalities(const fr_t *advice, uint64_t proof_stride, const uint64_t *pairs, uint64_t n_pairs, const uint64_t *ccells, const fr_t *cvals, uint64_t n_const, unsigned long long *bad) {
+    const uint32_t p = blockIdx.y; const fr_t *adv = advice + (uint64_t)p * proof_stride; unsigned long long b0 = 0, b1 = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_pairs + n_const; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (j < n_pairs) { if (!fr_eq(g_load_fr(adv + pairs[2 * j]), g_load_fr(adv + pairs[2 * j + 1]))) b0++; }
+        else { const uint64_t t = j - n_pairs; if (!fr_eq(g_load_fr(adv + ccells[t]), g_load_fr(cvals + t))) b1++; }
+    }
+    if (b0) atomicAdd(bad, b0);
+    if (b1) atomicAdd(bad + 1, b1);
+}
+int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proof_stride_cells, uint64_t n_proofs, const uint64_t *pairs, uint64_t n_pairs,
+                         const uint64_t *const_cells, const h2w_fr_t *const_values, uint64_t n_const, uint64_t bad_out[2], void *stream_) {
+    if (!advice_dev || !bad_out || (n_pairs && !pairs) || (n_const && (!const_cells || !const_values))) { set_error("h2w_check_equalities: null argument"); return -1; }
+    bad_out[0] = bad_out[1] = 0;
+    if (n_proofs == 0 || n_pairs + n_const == 0) return 0;
+    if (n_proofs > 65535) { set_error("h2w_check_equalities: too many proofs per call"); return -1; }
+    for (uint64_t i = 0; i < 2 * n_pairs; i++) if (pairs[i] >= n_cells) { set_error("h2w_check_equalities: equality refers to a cell outside the stream"); return -1; }
+    for (uint64_t i = 0; i < n_const; i++) if (const_cells[i] >= n_cells) { set_error("h2w_check_equalities: constant equality refers to a cell outside the stream"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    uint64_t *d_pairs = nullptr, *d_cc = nullptr; fr_t *d_cv = nullptr; unsigned long long *d_bad = nullptr;
+    H2W_HIP(hipMalloc((void **)&d_pairs, (n_pairs ? 2 * n_pairs : 1) * 8)); H2W_HIP(hipMalloc((void **)&d_cc, (n_const ? n_const : 1) * 8));
+    H2W_HIP(hipMalloc((void **)&d_cv, (n_const ? n_const : 1) * sizeof(fr_t))); H2W_HIP(hipMalloc((void **)&d_bad, 16));
+    if (n_pairs) H2W_HIP(hipMemcpyAsync(d_pairs, pairs, 2 * n_pairs * 8, hipMemcpyHostToDevice, stream));
+    if (n_const) { H2W_HIP(hipMemcpyAsync(d_cc, const_cells, n_const * 8, hipMemcpyHostToDevice, stream)); H2W_HIP(hipMemcpyAsync(d_cv, const_values, n_const * sizeof(fr_t), hipMemcpyHostToDevice, stream)); }
+    H2W_HIP(hipMemsetAsync(d_bad, 0, 16, stream));
+    hipLaunchKernelGGL(k_check_equalities, dim3(1024, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, d_pairs, n_pairs, d_cc, d_cv, n_const, d_bad);
+    unsigned long long h[2] = {0, 0};
+    H2W_HIP(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, stream));
+    H2W_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(d_pairs); (void)hipFree(d_cc); (void)hipFree(d_cv); (void)hipFree(d_bad);
+    bad_out[0] = h[0]; bad_out[1] = h[1];
+    return 0;
+}
 int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {
     if (!p || !workspace_dev || !host_status) { set_error("h2w_plan_status: null argument"); return -1; }
     size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);

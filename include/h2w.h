@@ -222,6 +222,13 @@ int h2w_check_constraints(h2w_plan *, const void *advice_dev, uint64_t proof_str
  * path: every rank needs the proofs (one broadcast) and nothing else.  The byte-wise union over the ranks is the full stream. */
 int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev,
                                 void *stream, int rank, int world);
+/* The rest of the restated MockProver: copy constraints (bad[0] = pairs whose two cells differ) and constant equalities (bad[1])
+ * over device advice streams.  The lists are static per shape: take them from an eager keygen context of the same shape
+ * (h2w_ctx_equalities / h2w_ctx_const_equalities).  Synchronises the stream. */
+int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proof_stride_cells, uint64_t n_proofs,
+                         const uint64_t *pairs, uint64_t n_pairs, const uint64_t *const_cells, const h2w_fr_t *const_values,
+                         uint64_t n_const, uint64_t bad[2], void *stream);
+
 /* Per-proof device status words.  0 = ok.  1 = GoldilocksChip::div by zero (reference asserts, base.rs:379), 2 = extension
  * inverse of zero (extension.rs:327), 3 = challenger input buffer overflow, 4 = the proof holds a word outside its field's
  * canonical range (a Goldilocks word >= p or a BN254 hash >= r: not representable by the reference's types; the cells are
