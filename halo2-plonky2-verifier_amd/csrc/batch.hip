@@ -13,6 +13,7 @@
 #include <string>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include "common.h"
 #include "valbackend.h"
 #include "coop.h"
@@ -595,13 +596,23 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
     A.bn_perm_cells = 4032; A.role_base = 0;
+    A.dbg_skip_perm = 0;
+#ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/): never defined in the product build, the results are garbage
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e ? atoi(e) : 0; } A.dbg_skip_perm = dbg; }
+#endif
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
     H2W_HIP(hipEventRecord(p->ev[0], stream));
-    static int dbg_skip = -1;      // timing experiments only (H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion) — results are then garbage
-    if (dbg_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); dbg_skip = e ? atoi(e) : 0; }
+    int dbg_skip = 0;
+#ifdef H2W_DEBUG_HOOKS   // H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion; H2W_DBG_SKIP_ALT="a,b": even calls mask a, odd calls mask b
+    {
+        static int env_skip = -1, alt_a = -1, alt_b = -1; static uint64_t call_no = 0;
+        if (env_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); env_skip = e ? atoi(e) : 0; }
+        if (alt_a == -1) { const char *e = getenv("H2W_DBG_SKIP_ALT"); if (!(e && sscanf(e, "%d,%d", &alt_a, &alt_b) == 2)) alt_a = -2; }
+        dbg_skip = alt_a >= 0 ? ((call_no++ & 1) ? alt_b : alt_a) : env_skip;
+    }
+#endif
     if (!(dbg_skip & 1)) { if (cm.starts) hipLaunchKernelGGL(k_prologue_coop<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_coop<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); }
     H2W_HIP(hipEventRecord(p->ev[3], stream));
     const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);

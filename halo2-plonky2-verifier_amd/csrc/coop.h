@@ -314,7 +314,11 @@ template <bool COLS> struct QuadSinkT {
 #pragma unroll
             for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) t[v] = src[pc]; }
 #pragma unroll
+#ifdef H2W_ABL_NOFLUSH      // timing-only ablation: the staged cells are read back but not written to memory
+            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np && t[v].x == 0x123456789abcull) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
+#else
             for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
+#endif
             if ((u + 4) * 4 >= np) break;
         }
     }
