@@ -44,7 +44,7 @@ def cpu_baseline(shape_args, hash_mode, lookup_bits, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as O
     sh = O.fibonacci_shape(shape_args[0], shape_args[1], rate_bits=shape_args[2], hash_mode=hash_mode, lookup_bits=lookup_bits)
-    k = O.synth_consts(0xC0FFEE)
+    k = O.published_consts()
     n, cells, t0 = 0, 0, time.perf_counter()
     while True:
         pr = O.synth_proof(sh, 0xF1B00000 + n)
@@ -104,14 +104,12 @@ def main():
     d, q, rb, desc = CONFIGS[args.config]
     hash_mode = 1 if args.hash == "bn254" else 0
     shape = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=hash_mode, lookup_bits=args.lookup_bits)
-    # Poseidon constants are caller inputs; synthetic (seeded) here — the real tables live in plonky2 / plonky2x.  Every 64-bit word
-    # is drawn below 2^60, so Goldilocks entries are canonical (< p) and every 4-word group is a canonical Fr (< 2^252 < r).
-    # (The oracle is not involved in the product path: it is imported by the cpu_baseline leg only.)
+    # Poseidon constants: the published plonky2 / circomlib parameter sets the reference links in (h2w_poseidon_published;
+    # pinned to published known-answer vectors in tests/test_poseidon_published.py).  The oracle is not involved in the
+    # product path: it is imported by the cpu_baseline leg only.
     import ctypes as C
     import numpy as np
-    rng = np.random.default_rng(0xC0FFEE)
-    consts = h2w.PoseidonConsts()
-    np.frombuffer((C.c_uint8 * C.sizeof(consts)).from_address(C.addressof(consts)), dtype=np.uint64)[:] = rng.integers(0, 1 << 60, C.sizeof(consts) // 8, dtype=np.uint64)
+    consts = h2w.published_consts()
     plan = api.Plan(shape, consts, local_rank)
 
     cell_bytes = plan.num_cells * 32

@@ -76,6 +76,7 @@ _av = C.POINTER(Assigned)
 _fr = C.POINTER(Fr)
 SYMBOLS = {
     "h2w_abi_version": (C.c_int, []),
+    "h2w_poseidon_published": (C.c_int, [C.POINTER(PoseidonConsts)]),
     "h2w_last_error": (C.c_char_p, []),
     "h2w_device_count": (C.c_int, []),
     "h2w_ctx_new": (_vp, [C.c_int, C.c_int, C.c_int]),
@@ -208,3 +209,11 @@ def last_error():
 def _ck(rc, what):
     if rc != 0:
         raise H2WError(f"{what}: {last_error()}")
+
+
+def published_consts():
+    """The published Poseidon parameter sets (plonky2 Goldilocks width 12; circomlib / plonky2x BN254 t = 4) the reference links in
+    from its dependencies (hash/poseidon/permutation.rs:2-7, hash/poseidon_bn254/permutation.rs:7-11): h2w_poseidon_published."""
+    k = PoseidonConsts()
+    _ck(lib().h2w_poseidon_published(C.byref(k)), "h2w_poseidon_published")
+    return k

@@ -14,6 +14,7 @@
 #include "records.h"
 #include "common.h"
 #include "keygen.h"
+#include "poseidon_tables.h"
 
 namespace h2w {
 
@@ -170,6 +171,7 @@ inline int kg_done(h2w_ctx *c, const char *fn) { if (c->keygen && c->mr.row != c
 extern "C" {
 
 int h2w_abi_version(void) { return H2W_ABI_VERSION; }
+int h2w_poseidon_published(h2w_poseidon_consts_t *out) { if (!out) { set_error("h2w_poseidon_published: null output"); return -1; } *out = H2W_POSEIDON_PUBLISHED; return 0; }
 const char *h2w_last_error(void) { return g_last_error.c_str(); }
 int h2w_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 

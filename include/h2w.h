@@ -78,6 +78,11 @@ typedef struct h2w_plan h2w_plan;
 int         h2w_abi_version(void);
 const char *h2w_last_error(void);
 int         h2w_device_count(void);              /* number of visible HIP devices (0 = none: every compute call fails) */
+/* The published parameter sets the reference links in from its dependencies: plonky2's Goldilocks Poseidon (width 12:
+ * ALL_ROUND_CONSTANTS, MDS_MATRIX_CIRC/_DIAG, FAST_PARTIAL_*; hash/poseidon/permutation.rs:2-7) and plonky2x's
+ * circomlib t = 4 PoseidonBN254 tables C/S/M/P (hash/poseidon_bn254/permutation.rs:7-11).  Pure data (no device needed);
+ * a caller may pass any other tables of the same layout instead. */
+int         h2w_poseidon_published(h2w_poseidon_consts_t *out);
 
 /* ------------------------------------------------------------------ 1. eager NativeChip level
  * replaces halo2-base Context + GateChip + RangeChip as used by field/native.rs.

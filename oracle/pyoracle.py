@@ -253,6 +253,33 @@ def synth_consts(seed=0xC0FFEE):
     return k
 
 
+def published_consts(path=None):
+    """The published Poseidon parameter sets (tests/golden/poseidon_published.json, made and known-answer-checked by
+    tools/gen_poseidon_constants.py) as the oracle's constant block."""
+    import json
+    path = path or os.path.join(_HERE, "..", "tests", "golden", "poseidon_published.json")
+    j = json.load(open(path))
+    g, b = j["goldilocks_w12"], j["bn254_t4"]
+    as_int = lambda x: int(x, 16) if isinstance(x, str) else int(x)
+    k = Consts()
+    for name in ("all_round_constants", "mds_circ", "mds_diag", "fast_partial_first_round_constant", "fast_partial_round_constants"):
+        for i, v in enumerate(g[name]):
+            getattr(k, name)[i] = as_int(v)
+    for name in ("fast_partial_round_initial_matrix", "fast_partial_round_w_hats", "fast_partial_round_vs"):
+        for i, row in enumerate(g[name]):
+            for jx, v in enumerate(row):
+                getattr(k, name)[i][jx] = as_int(v)
+    for i, v in enumerate(b["C"]):
+        k.bn_c[i] = Fr.from_int(as_int(v))
+    for i, v in enumerate(b["S"]):
+        k.bn_s[i] = Fr.from_int(as_int(v))
+    for i in range(4):
+        for jx in range(4):
+            k.bn_m[i][jx] = Fr.from_int(as_int(b["M"][i][jx]))
+            k.bn_p[i][jx] = Fr.from_int(as_int(b["P"][i][jx]))
+    return k
+
+
 def synth_proof(shape, seed):
     n = lib().orc_proof_words(C.byref(shape))
     buf = (C.c_uint64 * n)()

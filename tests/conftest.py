@@ -47,3 +47,10 @@ def consts(h2w, oracle):
     ko = oracle.synth_consts(0xC0FFEE)
     kh = h2w.PoseidonConsts.from_buffer_copy(bytes(ko))
     return ko, kh
+
+
+@pytest.fixture(scope="session")
+def published(h2w, oracle):
+    """The published Poseidon parameter sets: the oracle's copy from tests/golden/poseidon_published.json, the product's own
+    from h2w_poseidon_published (tests/test_poseidon_published.py pins both to published known-answer vectors)."""
+    return oracle.published_consts(), h2w.published_consts()

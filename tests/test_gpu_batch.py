@@ -79,6 +79,16 @@ def test_valid_fri_proofs(h2w, h2w_api, oracle, consts, mode):
     run_batch(h2w, h2w_api, oracle, consts, (9, 2, 1, mode), [33], valid=True, cap_height=2)     # one fold step
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+def test_published_poseidon_tables(h2w, h2w_api, oracle, published, mode):
+    """The batched path under the published parameter sets (plonky2 Goldilocks / circomlib BN254 tables, pinned to published
+    known-answer vectors in tests/test_poseidon_published.py): valid FRI instances with and without a fold step, and BASELINE
+    configs[0]'s shape (2^10 rows, 4 queries) on random words, byte for byte."""
+    run_batch(h2w, h2w_api, oracle, published, (6, 3, 1, mode), [41, 42], valid=True, cap_height=2)
+    run_batch(h2w, h2w_api, oracle, published, (9, 2, 1, mode), [43], valid=True, cap_height=2)
+    run_batch(h2w, h2w_api, oracle, published, (10, 4, 1, mode), [0xF1B00001])
+
+
 def test_config3_bn254_full(h2w, h2w_api, oracle, consts):
     """BASELINE.json configs[2]: 2^20 rows, 28 queries, cap_height 4, PoseidonBN254 Merkle — 28.58 M cells, every byte."""
     run_batch(h2w, h2w_api, oracle, consts, (20, 28, 1, 1), [0xF1B00003])

@@ -135,3 +135,25 @@ def test_fibonacci_stark_through_eager_boundary(h2w, h2w_api, oracle, consts, mo
         assert ctx.num_cells() == octx.num_cells()
         assert ctx.advice_bytes() == octx.advice_bytes()
         ctx.close(); octx.close()
+
+
+def test_permutations_reproduce_published_known_answers(h2w, h2w_api, oracle, published):
+    """Both permutation chips through the eager C-ABI with the published parameter sets (h2w_poseidon_published): the output
+    wires carry plonky2's published permute([0;12]) / permute([0..11]) / permute([-1;12]) vectors and circomlib's
+    poseidon([1,2,3]) (tests/golden/poseidon_published.json), and the GPU-expanded advice equals the oracle's."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poseidon_published.json")))
+    ko, kh = published; pr = Pair(h2w, h2w_api, oracle)
+    for v in gold["goldilocks_w12"]["permutation_vectors"][:4]:
+        st = [pr.gl_const(int(x, 16)) for x in v["in"]]
+        go, oo = (h2w.Assigned * 12)(), (oracle.AV * 12)()
+        assert pr.L.h2w_chip_gl_poseidon_permute(pr.p, C.byref(kh), pr.garr([x[0] for x in st]), go) == 0
+        pr.OL.orc_gl_poseidon_permute(pr.op, C.byref(ko), pr.oarr([x[1] for x in st]), oo)
+        assert [hex(g.int_value()) for g in go] == v["out"]
+    for v in gold["bn254_t4"]["permutation_vectors"]:
+        st = [pr.fr_const(int(x, 16)) for x in v["in"]]
+        go, oo = (h2w.Assigned * 4)(), (oracle.AV * 4)()
+        assert pr.L.h2w_chip_bn_poseidon_permute(pr.p, C.byref(kh), pr.garr([x[0] for x in st]), go) == 0
+        pr.OL.orc_bn_poseidon_permute(pr.op, C.byref(ko), pr.oarr([x[1] for x in st]), oo)
+        assert [hex(g.int_value()) for g in go] == v["out"]
+    pr.check()
