@@ -156,6 +156,12 @@ SYMBOLS = {
     "h2w_plan_last_timing": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "h2w_plan_timing": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
     "h2w_plan_num_record_cells": (C.c_uint64, [_vp]),
+    "h2w_prover_new": (_vp, [C.POINTER(Shape), C.POINTER(PoseidonConsts), C.c_int]),
+    "h2w_prover_free": (None, [_vp]),
+    "h2w_prover_num_polys": (C.c_uint64, [_vp]),
+    "h2w_prover_proof_words": (C.c_uint64, [_vp]),
+    "h2w_prove_fri": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), _vp, _vp]),
+    "h2w_prover_timing": (C.c_int, [_vp, C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -315,3 +315,38 @@ class Plan:
         ms = (C.c_float * 5)()
         _ck(self.L.h2w_plan_last_timing(self.p, ms), "h2w_plan_last_timing")
         return tuple(ms)
+
+
+class Prover:
+    """Synthetic valid FRI instances generated on the GPU (h2w_prover_* / h2w_prove_fri): the step before the
+    path.  The reference gets its proofs from starky's prover (stark/mod.rs:405-426); the committed polynomials are inputs."""
+
+    def __init__(self, shape, consts, device_id=0):
+        self.L = lib()
+        self.shape, self.consts = shape, consts
+        self.p = self.L.h2w_prover_new(C.byref(shape), C.byref(consts), device_id)
+        if not self.p:
+            raise H2WError("h2w_prover_new: " + last_error())
+        self.num_polys = int(self.L.h2w_prover_num_polys(self.p))
+        self.proof_words = int(self.L.h2w_prover_proof_words(self.p))
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.h2w_prover_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove(self, coeffs_ptr, public_inputs, proof_ptr, stream=0):
+        """coeffs_ptr: device [num_polys][2^degree_bits] u64; public_inputs: sequence of n_pis ints; proof_ptr: device proof_words u64."""
+        pis = (C.c_uint64 * max(len(public_inputs), 1))(*public_inputs)
+        _ck(self.L.h2w_prove_fri(self.p, coeffs_ptr, pis, proof_ptr, stream), "h2w_prove_fri")
+
+    def timing(self):
+        ms = (C.c_float * 7)()
+        _ck(self.L.h2w_prover_timing(self.p, ms), "h2w_prover_timing")
+        return dict(zip(("lde", "commit", "openings_quotient", "fri_commit", "pow", "queries", "total_wall"), [float(x) for x in ms]))

@@ -1,0 +1,652 @@
+// prover.hip — SURVEY §8(f) row 3: the step BEFORE the path.  Valid synthetic FRI instances generated on the GPU, written in
+// the flat proof layout h2w_fri_witness_batch consumes (chips.h ProofLayout = WitnessChip load order, witness/mod.rs:236-294).
+//
+// What the reference gets from starky's prover (stark/mod.rs:405-426) is produced here with the plonky2 prover conventions the
+// verifier gadget checks (fri/mod.rs:148-444, merkle/mod.rs:57-115, challenger/mod.rs:168-222):
+//   * PolynomialBatch: LDE on the coset 7<w>, |<w>| = 2^(degree_bits + rate_bits); Merkle leaves in bit-reversed order
+//     (a decimation-in-frequency NTT leaves its output in exactly that order, so nothing is ever permuted);
+//   * transcript order trace cap, permutation challenges, permutation cap, alphas, quotient cap, zeta, openings, alpha,
+//     commit-phase caps / betas, final polynomial, proof-of-work witness, query indices;
+//   * batched quotient sum_b (G_b - G_b(z_b)) / (X - z_b) with the verifier's alpha shifts (fri/mod.rs:169-220), as a suffix scan;
+//   * commit phase: leaves of 2^arity_bits extension evaluations, coefficient folding with beta, shift <- shift^arity.
+// Device work: NTTs, leaf hashing and tree levels (one lane per permutation), opening evaluation (blocked Horner), the quotient
+// scan, folding, the proof-of-work search and the query gather.  Host work: the serial sponge (tens of permutations).
+// All arithmetic is exact integer arithmetic, so any schedule gives the oracle's (oracle/prover.inc) words bit for bit.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "chips.h"
+#include "common.h"
+
+namespace h2w {
+namespace {
+
+struct BnMont { fr_t c[88], s[392], m[4][4], p[4][4]; };                 // PoseidonBN254 tables in Montgomery form (x * 2^261)
+struct ProverConsts { h2w_poseidon_consts_t k; BnMont bn; fr_t r2; uint64_t ninv; };
+struct H4 { uint64_t w[4]; };
+
+HD gle_t gle_add(gle_t a, gle_t b) { gle_t r; r.c[0] = gl_add(a.c[0], b.c[0]); r.c[1] = gl_add(a.c[1], b.c[1]); return r; }
+HD gle_t gle_sub(gle_t a, gle_t b) { gle_t r; r.c[0] = gl_sub(a.c[0], b.c[0]); r.c[1] = gl_sub(a.c[1], b.c[1]); return r; }
+HD gle_t gle_scale(gle_t a, uint64_t b) { gle_t r; r.c[0] = gl_mul(a.c[0], b); r.c[1] = gl_mul(a.c[1], b); return r; }
+HD gle_t gle_of(uint64_t a) { gle_t r; r.c[0] = a; r.c[1] = 0; return r; }
+HD gle_t gle_pow(gle_t a, uint64_t e) { gle_t acc = gle_of(1); while (e) { if (e & 1) acc = gle_mul(acc, a); a = gle_mul(a, a); e >>= 1; } return acc; }
+
+// ---------------------------------------------------------------- Goldilocks Poseidon, plonky2 "fast" layout (hash/poseidon/permutation.rs:43-314)
+HDN inline void gl_permute(const h2w_poseidon_consts_t *k, uint64_t *st) {
+    int rc = 0;
+    for (int half = 0; half < 2; half++) {
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], k->fast_partial_first_round_constant[i]);
+            uint64_t res[12];
+#pragma unroll
+            for (int c = 0; c < 12; c++) res[c] = c == 0 ? st[0] : 0;
+#pragma unroll
+            for (int r = 1; r < 12; r++) {
+#pragma unroll
+                for (int c = 1; c < 12; c++) res[c] = gl_muladd(k->fast_partial_round_initial_matrix[r - 1][c - 1], st[r], res[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 12; c++) st[c] = res[c];
+            const uint64_t m00 = gl_add(k->mds_circ[0], k->mds_diag[0]);
+#pragma unroll 1
+            for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
+                uint64_t x = st[0], x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x6 = gl_mul(x4, x2);
+                const uint64_t s0 = gl_add(gl_mul(x6, x), k->fast_partial_round_constants[r]);
+                uint64_t d = gl_mul(m00, s0);
+#pragma unroll
+                for (int i = 1; i < 12; i++) d = gl_muladd(k->fast_partial_round_w_hats[r][i - 1], st[i], d);
+#pragma unroll
+                for (int i = 1; i < 12; i++) st[i] = gl_muladd(k->fast_partial_round_vs[r][i - 1], s0, st[i]);
+                st[0] = d;
+            }
+            rc += N_PARTIAL_ROUNDS;
+        }
+#pragma unroll 1
+        for (int f = 0; f < HALF_N_FULL_ROUNDS; f++) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                uint64_t x = gl_add(st[i], k->all_round_constants[i + 12 * rc]);
+                uint64_t x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x6 = gl_mul(x4, x2); st[i] = gl_mul(x6, x);
+            }
+            uint64_t res[12];
+#pragma unroll
+            for (int r = 0; r < 12; r++) {
+                uint64_t acc = 0;
+#pragma unroll
+                for (int i = 0; i < 12; i++) acc = gl_muladd(k->mds_circ[i], st[(i + r) % 12], acc);
+                res[r] = gl_muladd(k->mds_diag[r], st[r], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 12; r++) st[r] = res[r];
+            rc++;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- PoseidonBN254 (hash/poseidon_bn254/permutation.rs:48-203), Montgomery-form state
+HNI fr_t mmul(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }
+HDN inline fr_t bn_pow5(fr_t x, uint64_t ni) { fr_t x2 = mmul(x, x, ni), x4 = mmul(x2, x2, ni); return mmul(x4, x, ni); }
+HDN inline void bn_mix(fr_t *st, const fr_t m[4][4], uint64_t ni) {
+    fr_t ns[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ns[i] = mmul(m[0][i], st[0], ni);
+#pragma unroll
+        for (int j = 1; j < 4; j++) ns[i] = fr_add(ns[i], mmul(m[j][i], st[j], ni));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) st[i] = ns[i];
+}
+HDN inline void bn_permute_m(const ProverConsts *K, fr_t *st) {
+    const uint64_t ni = K->ninv; const BnMont &B = K->bn;
+#pragma unroll
+    for (int j = 0; j < 4; j++) st[j] = fr_add(st[j], B.c[j]);
+    for (int half = 0; half < 2; half++) {
+        if (half == 1) {
+#pragma unroll 1
+            for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                st[0] = fr_add(bn_pow5(st[0], ni), B.c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]);
+                fr_t ns0 = mmul(B.s[7 * r], st[0], ni);
+#pragma unroll
+                for (int j = 1; j < 4; j++) ns0 = fr_add(ns0, mmul(B.s[7 * r + j], st[j], ni));
+#pragma unroll
+                for (int kk = 1; kk < 4; kk++) st[kk] = fr_add(st[kk], mmul(B.s[7 * r + 4 + kk - 1], st[0], ni));
+                st[0] = ns0;
+            }
+        }
+#pragma unroll 1
+        for (int i = 0; i < BN_FULL_ROUNDS / 2 - 1; i++) {
+            const int it = half == 0 ? (i + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + i * BN_WIDTH;
+#pragma unroll
+            for (int j = 0; j < 4; j++) st[j] = fr_add(bn_pow5(st[j], ni), B.c[it + j]);
+            bn_mix(st, B.m, ni);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) st[j] = bn_pow5(st[j], ni);
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) st[j] = fr_add(st[j], B.c[(BN_FULL_ROUNDS / 2) * BN_WIDTH + j]);
+            bn_mix(st, B.p, ni);
+        } else bn_mix(st, B.m, ni);
+    }
+}
+HDN inline fr_t to_mont(const ProverConsts *K, fr_t x) { return mmul(x, K->r2, K->ninv); }
+HDN inline fr_t from_mont(const ProverConsts *K, fr_t x) { return mmul(x, fr_from_u64(1), K->ninv); }
+
+// ---------------------------------------------------------------- hashers (hash/poseidon/hash.rs:63-215, hash/poseidon_bn254/hash.rs:67-210): a hash is 4 words
+template <int MAXN> HDN inline H4 hash_no_pad(const ProverConsts *K, int mode, const uint64_t (&in)[MAXN], int n) {
+    H4 h;
+    if (mode == 0) {
+        uint64_t st[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = 0;
+#pragma unroll
+        for (int off = 0; off < MAXN; off += SPONGE_RATE) {
+            if (off < n) {
+#pragma unroll
+                for (int i = 0; i < SPONGE_RATE; i++) if (off + i < MAXN && off + i < n) st[i] = in[off + i];
+                gl_permute(&K->k, st);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) h.w[i] = st[i];
+    } else {
+        fr_t st[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) st[i] = fr_zero();
+#pragma unroll
+        for (int off = 0; off < MAXN; off += 9) {
+            if (off < n) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int o = off + 3 * j;
+                    if (o < MAXN && o < n) {
+                        fr_t v = fr_zero();
+#pragma unroll
+                        for (int l = 0; l < 3; l++) if (o + l < MAXN && o + l < n) v.l[l] = in[o + l];
+                        st[j + 1] = to_mont(K, v);
+                    }
+                }
+                bn_permute_m(K, st);
+            }
+        }
+        const fr_t o = from_mont(K, st[0]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) h.w[i] = o.l[i];
+    }
+    return h;
+}
+template <int MAXN> HDN inline H4 hash_or_noop(const ProverConsts *K, int mode, const uint64_t (&in)[MAXN], int n) {
+    if (n > (mode == 0 ? 4 : 3)) return hash_no_pad<MAXN>(K, mode, in, n);
+    H4 h;
+#pragma unroll
+    for (int i = 0; i < 4; i++) h.w[i] = (i < MAXN && i < n) ? in[i < MAXN ? i : 0] : 0;
+    return h;
+}
+HDN inline H4 two_to_one(const ProverConsts *K, int mode, const H4 &l, const H4 &r) {
+    H4 h;
+    if (mode == 0) {
+        uint64_t st[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { st[i] = l.w[i]; st[4 + i] = r.w[i]; st[8 + i] = 0; }
+        gl_permute(&K->k, st);
+#pragma unroll
+        for (int i = 0; i < 4; i++) h.w[i] = st[i];
+    } else {
+        fr_t st[4], a, b;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a.l[i] = l.w[i]; b.l[i] = r.w[i]; }
+        st[0] = fr_zero(); st[1] = fr_zero(); st[2] = to_mont(K, a); st[3] = to_mont(K, b);
+        bn_permute_m(K, st);
+        const fr_t o = from_mont(K, st[0]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) h.w[i] = o.l[i];
+    }
+    return h;
+}
+
+// ================================================================= kernels
+__global__ void k_twiddles(uint64_t *tw, uint64_t half_n, uint64_t w) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < half_n) tw[j] = gl_exp(w, j);
+}
+// out[p][i] = coef[p][i] * shift^i for i < nc, 0 above (zero padding = low-degree extension)
+__global__ void k_scale_pad(const uint64_t *coef, uint64_t nc, uint64_t shift, uint64_t n, uint64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+    if (i < n) out[p * n + i] = i < nc ? gl_mul(coef[p * nc + i], gl_exp(shift, i)) : 0;
+}
+// one decimation-in-frequency stage (block length len = 2^s) of every array of the batch; tw[j << tw_shift] = w_len^j
+__global__ void k_dif_stage(uint64_t *a, uint64_t n, int s, const uint64_t *tw, int tw_shift) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n / 2) return;
+    uint64_t *x = a + (uint64_t)blockIdx.y * n;
+    const uint64_t half = 1ull << (s - 1), blk = t >> (s - 1), j = t & (half - 1), i0 = (blk << s) + j, i1 = i0 + half;
+    const uint64_t u = x[i0], v = x[i1];
+    x[i0] = gl_add(u, v); x[i1] = gl_mul(gl_sub(u, v), tw[j << tw_shift]);
+}
+// the last tb stages (len = 2^tb .. 2) inside LDS tiles of 2^tb contiguous elements
+constexpr int NTT_TILE_BITS = 11;
+__global__ __launch_bounds__(256) void k_dif_local(uint64_t *a, uint64_t n, int tb, const uint64_t *tw, int max_bits) {
+    __shared__ uint64_t tile[1 << NTT_TILE_BITS];
+    const uint32_t T = 1u << tb;
+    uint64_t *x = a + (uint64_t)blockIdx.y * n + (uint64_t)blockIdx.x * T;
+    for (uint32_t i = threadIdx.x; i < T; i += 256) tile[i] = x[i];
+    __syncthreads();
+    for (int s = tb; s >= 1; s--) {
+        const uint32_t half = 1u << (s - 1);
+        for (uint32_t t = threadIdx.x; t < T / 2; t += 256) {
+            const uint32_t blk = t >> (s - 1), j = t & (half - 1), i0 = (blk << s) + j, i1 = i0 + half;
+            const uint64_t u = tile[i0], v = tile[i1];
+            tile[i0] = gl_add(u, v); tile[i1] = gl_mul(gl_sub(u, v), tw[(uint64_t)j << (max_bits - s)]);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < T; i += 256) x[i] = tile[i];
+}
+// leaf j of an initial oracle = hash_or_noop(values of its polynomials at position j of the bit-reversed LDE)
+__global__ void k_leaves_initial(const ProverConsts *K, int mode, const uint64_t *vals, int npoly, uint64_t n, H4 *leaves) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint64_t buf[MAX_BATCH_POLYS];
+#pragma unroll
+    for (int p = 0; p < MAX_BATCH_POLYS; p++) buf[p] = p < npoly ? vals[(uint64_t)p * n + j] : 0;
+    leaves[j] = hash_or_noop<MAX_BATCH_POLYS>(K, mode, buf, npoly);
+}
+// commit-phase leaf j = hash of the 2^ab extension evaluations j*2^ab .. (v0 / v1: the two coordinates, bit-reversed order)
+__global__ void k_leaves_fri(const ProverConsts *K, int mode, const uint64_t *v0, const uint64_t *v1, int ab, uint64_t nl, H4 *leaves) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nl) return;
+    uint64_t buf[2 * MAX_ARITY]; const int ar = 1 << ab;
+#pragma unroll
+    for (int t = 0; t < MAX_ARITY; t++) { buf[2 * t] = t < ar ? v0[(j << ab) + t] : 0; buf[2 * t + 1] = t < ar ? v1[(j << ab) + t] : 0; }
+    leaves[j] = hash_or_noop<2 * MAX_ARITY>(K, mode, buf, 2 * ar);
+}
+__global__ void k_tree_level(const ProverConsts *K, int mode, const H4 *in, H4 *out, uint64_t m) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    out[i] = two_to_one(K, mode, in[2 * i], in[2 * i + 1]);
+}
+// partial[p][block] = sum over the block's coefficients c_i x^i (blocked Horner, then a block reduction)
+constexpr int EVAL_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void k_eval_partial(const uint64_t *coef, uint64_t N, gle_t x, gle_t *partial) {
+    __shared__ gle_t red[256];
+    const uint64_t p = blockIdx.y, base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * EVAL_PER_THREAD;
+    gle_t acc = gle_of(0);
+    if (base < N) {
+        const uint64_t *c = coef + p * N + base;
+        for (int i = EVAL_PER_THREAD - 1; i >= 0; i--) acc = gle_add(gle_mul(acc, x), gle_of(base + i < N ? c[i] : 0));
+        acc = gle_mul(acc, gle_pow(x, base));
+    }
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] = gle_add(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) partial[p * gridDim.x + blockIdx.x] = red[0];
+}
+// batched quotient, step 1: T[m] = G[m] z^m with G = sum_i alpha^i f_i (minus G(z) at m = 0); block sums
+struct QuotArgs { const uint64_t *coef; uint64_t N; int npoly; gle_t ap[MAX_BATCH_POLYS]; gle_t gz, z, zinv, an; };
+constexpr int SCAN_PER_THREAD = 8, SCAN_TILE = 256 * SCAN_PER_THREAD;
+__global__ __launch_bounds__(256) void k_quot_terms(QuotArgs A, gle_t *T, gle_t *totals) {
+    __shared__ gle_t red[256];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    gle_t sum = gle_of(0);
+    if (base < A.N) {
+        gle_t zp = gle_pow(A.z, base);
+        for (int e = 0; e < SCAN_PER_THREAD && base + e < A.N; e++) {
+            const uint64_t m = base + e;
+            gle_t g = gle_of(0);
+            for (int i = 0; i < A.npoly; i++) g = gle_add(g, gle_scale(A.ap[i], A.coef[(uint64_t)i * A.N + m]));
+            if (m == 0) g = gle_sub(g, A.gz);
+            const gle_t t = gle_mul(g, zp);
+            T[m] = t; sum = gle_add(sum, t); zp = gle_mul(zp, A.z);
+        }
+    }
+    red[threadIdx.x] = sum; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] = gle_add(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) totals[blockIdx.x] = red[0];
+}
+// step 2: carry[b] = sum of the totals of the blocks after b
+__global__ void k_suffix_totals(const gle_t *totals, gle_t *carry, int nblk) {
+    if (blockIdx.x || threadIdx.x) return;
+    gle_t acc = gle_of(0);
+    for (int b = nblk - 1; b >= 0; b--) { carry[b] = acc; acc = gle_add(acc, totals[b]); }
+}
+// step 3: H[j] = sum_{m >= j} T[m];  Q[j-1] = H[j] z^-j;  F[j-1] = F[j-1] * alpha^{n_b} + Q[j-1]  (Q[N-1] = 0)
+__global__ __launch_bounds__(256) void k_quot_finish(QuotArgs A, const gle_t *T, const gle_t *carry, gle_t *F) {
+    __shared__ gle_t tot[256];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    gle_t loc[SCAN_PER_THREAD]; gle_t acc = gle_of(0);
+#pragma unroll
+    for (int e = SCAN_PER_THREAD - 1; e >= 0; e--) { if (base + e < A.N) acc = gle_add(acc, T[base + e]); loc[e] = acc; }
+    tot[threadIdx.x] = acc; __syncthreads();
+    // suffix sums over the threads of the block (exclusive), serially by one wave-sized strided pass is not needed: 256 adds by thread 0
+    if (threadIdx.x == 0) { gle_t run = carry[blockIdx.x]; for (int t = 255; t >= 0; t--) { const gle_t mine = tot[t]; tot[t] = run; run = gle_add(run, mine); } }
+    __syncthreads();
+    const gle_t after = tot[threadIdx.x];
+    if (base < A.N) {
+        gle_t zi = gle_pow(A.zinv, base);
+#pragma unroll
+        for (int e = 0; e < SCAN_PER_THREAD; e++) {
+            const uint64_t j = base + e;
+            if (j < A.N) {
+                if (j >= 1) { const gle_t q = gle_mul(gle_add(loc[e], after), zi); F[j - 1] = gle_add(gle_mul(F[j - 1], A.an), q); }
+                if (j == A.N - 1) F[j] = gle_mul(F[j], A.an);
+                zi = gle_mul(zi, A.zinv);
+            }
+        }
+    }
+}
+// v0[i] = F[i].c0 shift^i, v1[i] = F[i].c1 shift^i (the coset is in the base field: the two coordinates transform separately)
+__global__ void k_split_scale(const gle_t *F, uint64_t n, uint64_t shift, uint64_t *v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = gl_exp(shift, i); const gle_t f = F[i];
+    v[i] = gl_mul(f.c[0], s); v[n + i] = gl_mul(f.c[1], s);
+}
+__global__ void k_fold(const gle_t *Fin, gle_t *Fout, uint64_t nl, int ab, gle_t beta) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nl) return;
+    gle_t acc = gle_of(0);
+    for (int t = (1 << ab) - 1; t >= 0; t--) acc = gle_add(gle_mul(acc, beta), Fin[(j << ab) + t]);
+    Fout[j] = acc;
+}
+// proof of work: the smallest witness whose challenge has pow_bits leading zero bits (challenger/mod.rs:92-108 pops the LAST rate word)
+struct PowArgs { uint64_t state[12]; uint64_t tail[SPONGE_RATE]; int ntail, pow_bits; uint64_t first; };
+__global__ void k_pow(const ProverConsts *K, PowArgs A, unsigned long long *best) {
+    const uint64_t w = A.first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t st[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = A.state[i];
+#pragma unroll
+    for (int i = 0; i < SPONGE_RATE; i++) if (i < A.ntail) st[i] = A.tail[i]; else if (i == A.ntail) st[i] = w;
+    gl_permute(&K->k, st);
+    if (A.pow_bits == 0 || (st[SPONGE_RATE - 1] >> (64 - A.pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
+}
+// query openings: one block per query
+struct GatherArgs {
+    const uint64_t *lde; uint64_t L; int lb, capb, no, npoly[3], poly0[3]; const H4 *tree[3];
+    int n_steps, ab[MAX_STEPS]; const uint64_t *fv[MAX_STEPS]; uint64_t fn[MAX_STEPS]; const H4 *ftree[MAX_STEPS];
+    uint64_t *proof; uint64_t q_base, q_words, init_off[3], step_off[MAX_STEPS]; const uint64_t *x_index;
+};
+HD uint64_t level_off(int bits, int l) { return (2ull << bits) - (2ull << (bits - l)); }     // hashes before level l of a tree with 2^bits leaves
+__global__ void k_gather(GatherArgs G) {
+    uint64_t *w = G.proof + G.q_base + (uint64_t)blockIdx.x * G.q_words;
+    const uint64_t x = G.x_index[blockIdx.x];
+    for (int o = 0; o < G.no; o++) {
+        uint64_t *wo = w + G.init_off[o];
+        for (int p = threadIdx.x; p < G.npoly[o]; p += blockDim.x) wo[p] = G.lde[(uint64_t)(G.poly0[o] + p) * G.L + x];
+        for (int l = threadIdx.x; l < G.lb - G.capb; l += blockDim.x) {
+            const H4 h = G.tree[o][level_off(G.lb, l) + ((x >> l) ^ 1)];
+            for (int i = 0; i < 4; i++) wo[G.npoly[o] + 4 * l + i] = h.w[i];
+        }
+    }
+    uint64_t idx = x; int bits = G.lb;
+    for (int st = 0; st < G.n_steps; st++) {
+        const int ab = G.ab[st], ar = 1 << ab; const uint64_t coset = idx >> ab; bits -= ab;
+        uint64_t *ws = w + G.step_off[st];
+        for (int t = threadIdx.x; t < ar; t += blockDim.x) { ws[2 * t] = G.fv[st][(coset << ab) + t]; ws[2 * t + 1] = G.fv[st][G.fn[st] + (coset << ab) + t]; }
+        for (int l = threadIdx.x; l < bits - G.capb; l += blockDim.x) {
+            const H4 h = G.ftree[st][level_off(bits, l) + ((coset >> l) ^ 1)];
+            for (int i = 0; i < 4; i++) ws[2 * ar + 4 * l + i] = h.w[i];
+        }
+        idx = coset;
+    }
+}
+
+// ================================================================= host: transcript (challenger/mod.rs:45-277) and driver
+struct HostChallenger {
+    const h2w_poseidon_consts_t *k; uint64_t state[12]; std::vector<uint64_t> in; uint64_t out[SPONGE_RATE]; int n_out;
+    explicit HostChallenger(const h2w_poseidon_consts_t *kk) : k(kk), n_out(0) { memset(state, 0, sizeof(state)); }
+    void observe(uint64_t v) { n_out = 0; in.push_back(v); }
+    void observe_hash(int mode, const H4 &h) {
+        if (mode == 0) { for (int i = 0; i < 4; i++) observe(h.w[i]); return; }
+        fr_t v; for (int i = 0; i < 4; i++) v.l[i] = h.w[i];
+        for (int i = 0; i < 5; i++) observe(fr_bits(v, 56 * i, 56));                       // hash/poseidon_bn254/hash.rs:31-43
+    }
+    void observe_ext(const gle_t &e) { observe(e.c[0]); observe(e.c[1]); }
+    void absorb() {
+        if (in.empty()) return;
+        for (size_t off = 0; off < in.size(); off += SPONGE_RATE) {
+            const size_t len = in.size() - off < (size_t)SPONGE_RATE ? in.size() - off : (size_t)SPONGE_RATE;
+            memcpy(state, in.data() + off, len * 8); gl_permute(k, state);
+        }
+        memcpy(out, state, sizeof(out)); n_out = SPONGE_RATE; in.clear();
+    }
+    uint64_t challenge() {
+        absorb();
+        if (n_out == 0) { gl_permute(k, state); memcpy(out, state, sizeof(out)); n_out = SPONGE_RATE; }
+        return out[--n_out];
+    }
+    gle_t ext_challenge() { gle_t r; r.c[0] = challenge(); r.c[1] = challenge(); return r; }
+};
+
+}  // namespace
+}  // namespace h2w
+
+using namespace h2w;
+
+struct h2w_prover {
+    h2w_shape_t shape; Derived d; ProofLayout pl; int device = 0;
+    ProverConsts hk; ProverConsts *dk = nullptr;
+    int np = 0, poly0[3] = {0, 0, 0};
+    uint64_t N = 0, L = 0;
+    uint64_t *tw = nullptr, *lde = nullptr, *fv[MAX_STEPS] = {nullptr}, *x_index = nullptr;
+    H4 *tree[3] = {nullptr, nullptr, nullptr}, *ftree[MAX_STEPS] = {nullptr};
+    gle_t *Fa = nullptr, *Fb = nullptr, *T = nullptr, *totals = nullptr, *carry = nullptr, *partial = nullptr;
+    unsigned long long *best = nullptr;
+    hipEvent_t ev[8] = {nullptr};
+    float ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    int eval_blocks = 0, scan_blocks = 0;
+};
+
+namespace {
+inline unsigned blocks(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+// in-place DIF NTT of `count` arrays of 2^bits words each: natural order in, bit-reversed order out
+void ntt_dif(const h2w_prover *p, uint64_t *a, int bits, int count, hipStream_t s) {
+    const uint64_t n = 1ull << bits; const int tb = bits < NTT_TILE_BITS ? bits : NTT_TILE_BITS;
+    for (int st = bits; st > tb; st--) hipLaunchKernelGGL(k_dif_stage, dim3(blocks(n / 2, 256), (unsigned)count), dim3(256), 0, s, a, n, st, p->tw, p->d.lde_bits - st);
+    if (tb >= 1) hipLaunchKernelGGL(k_dif_local, dim3((unsigned)(n >> tb), (unsigned)count), dim3(256), 0, s, a, n, tb, p->tw, p->d.lde_bits);
+}
+// all levels above the leaves up to the cap (level bits - capb)
+void build_tree(const h2w_prover *p, H4 *base, int bits, hipStream_t s) {
+    for (int l = 1; l <= bits - p->shape.cap_height; l++) {
+        const uint64_t m = 1ull << (bits - l);
+        hipLaunchKernelGGL(k_tree_level, dim3(blocks(m, 64)), dim3(64), 0, s, p->dk, p->shape.hash_mode, base + level_off(bits, l - 1), base + level_off(bits, l), m);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+h2w_prover *h2w_prover_new(const h2w_shape_t *shape, const h2w_poseidon_consts_t *consts, int device_id) {
+    if (!shape || !consts) { set_error("h2w_prover_new: null argument"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device: libh2w has no CPU fallback"); return nullptr; }
+    const Derived d = derive_shape(*shape);
+    if (d.lde_bits > 24 || d.lde_bits < 1 || shape->cap_height > d.lde_bits || shape->n_pis > 64 || shape->num_queries > 4096 || shape->num_queries < 0 ||
+        shape->n_cols + shape->n_perm_z + shape->n_quotient > MAX_BATCH_POLYS || shape->n_cols > MAX_BATCH_POLYS || shape->arity_bits > 4 || shape->arity_bits < 1) {
+        set_error("h2w_prover_new: unsupported shape"); return nullptr;
+    }
+    h2w_prover *p = new h2w_prover();
+    p->shape = *shape; p->d = d; p->pl = proof_layout(*shape, d); p->device = device_id;
+    p->N = 1ull << shape->degree_bits; p->L = 1ull << d.lde_bits;
+    for (int o = 0; o < d.n_oracles; o++) { p->poly0[o] = p->np; p->np += d.oracle_polys[o]; }
+    // constants: caller's tables + PoseidonBN254 tables in Montgomery form
+    const FrParams P = fr_params_init();
+    p->hk.k = *consts; p->hk.r2 = P.r2; p->hk.ninv = P.ninv;
+    for (int i = 0; i < 88; i++) p->hk.bn.c[i] = fr_mont_mul(consts->bn_c[i], P.r2, P.ninv);
+    for (int i = 0; i < 392; i++) p->hk.bn.s[i] = fr_mont_mul(consts->bn_s[i], P.r2, P.ninv);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { p->hk.bn.m[i][j] = fr_mont_mul(consts->bn_m[i][j], P.r2, P.ninv); p->hk.bn.p[i][j] = fr_mont_mul(consts->bn_p[i][j], P.r2, P.ninv); }
+    bool ok = hipSetDevice(device_id) == hipSuccess;
+    auto dm = [&](void **q, size_t bytes) { if (ok && hipMalloc(q, bytes ? bytes : 8) != hipSuccess) ok = false; };
+    dm((void **)&p->dk, sizeof(ProverConsts));
+    dm((void **)&p->tw, (p->L / 2 ? p->L / 2 : 1) * 8);
+    dm((void **)&p->lde, (size_t)p->np * p->L * 8);
+    for (int o = 0; o < d.n_oracles; o++) dm((void **)&p->tree[o], 2 * p->L * sizeof(H4));
+    dm((void **)&p->Fa, p->L * sizeof(gle_t)); dm((void **)&p->Fb, p->L * sizeof(gle_t)); dm((void **)&p->T, p->N * sizeof(gle_t));
+    p->scan_blocks = (int)blocks(p->N, SCAN_TILE); p->eval_blocks = (int)blocks(p->N, 256 * EVAL_PER_THREAD);
+    dm((void **)&p->totals, p->scan_blocks * sizeof(gle_t)); dm((void **)&p->carry, p->scan_blocks * sizeof(gle_t));
+    dm((void **)&p->partial, (size_t)2 * p->np * p->eval_blocks * sizeof(gle_t));
+    { uint64_t n = p->L; for (int st = 0; st < d.n_steps; st++) { dm((void **)&p->fv[st], 2 * n * 8); dm((void **)&p->ftree[st], 2 * (n >> d.arity[st]) * sizeof(H4)); n >>= d.arity[st]; } }
+    dm((void **)&p->x_index, (size_t)shape->num_queries * 8); dm((void **)&p->best, 8);
+    for (int i = 0; i < 8 && ok; i++) ok = hipEventCreate(&p->ev[i]) == hipSuccess;
+    if (ok) ok = hipMemcpy(p->dk, &p->hk, sizeof(ProverConsts), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && p->L >= 2) { hipLaunchKernelGGL(k_twiddles, dim3(blocks(p->L / 2, 256)), dim3(256), 0, 0, p->tw, p->L / 2, gl_primitive_root_of_unity(d.lde_bits)); ok = hipDeviceSynchronize() == hipSuccess; }
+    if (!ok) { set_error(std::string("h2w_prover_new: ") + hipGetErrorString(hipGetLastError())); h2w_prover_free(p); return nullptr; }
+    return p;
+}
+void h2w_prover_free(h2w_prover *p) {
+    if (!p) return;
+    hipFree(p->dk); hipFree(p->tw); hipFree(p->lde); hipFree(p->Fa); hipFree(p->Fb); hipFree(p->T); hipFree(p->totals); hipFree(p->carry);
+    hipFree(p->partial); hipFree(p->x_index); hipFree(p->best);
+    for (int o = 0; o < 3; o++) hipFree(p->tree[o]);
+    for (int st = 0; st < MAX_STEPS; st++) { hipFree(p->fv[st]); hipFree(p->ftree[st]); }
+    for (int i = 0; i < 8; i++) if (p->ev[i]) hipEventDestroy(p->ev[i]);
+    delete p;
+}
+uint64_t h2w_prover_num_polys(const h2w_prover *p) { return p ? (uint64_t)p->np : 0; }
+uint64_t h2w_prover_proof_words(const h2w_prover *p) { return p ? p->pl.total : 0; }
+
+int h2w_prove_fri(h2w_prover *p, const uint64_t *coeffs_dev, const uint64_t *public_inputs, uint64_t *proof_dev, void *stream_) {
+    if (!p || !coeffs_dev || !proof_dev || (p->shape.n_pis > 0 && !public_inputs)) { set_error("h2w_prove_fri: null argument"); return -1; }
+    const auto t_begin = std::chrono::steady_clock::now();
+    hipStream_t s = (hipStream_t)stream_;
+    const h2w_shape_t &sh = p->shape; const Derived &d = p->d; const ProofLayout &pl = p->pl;
+    const int mode = sh.hash_mode, lb = d.lde_bits, capb = sh.cap_height, cs = d.cap_size, no = d.n_oracles;
+    const uint64_t N = p->N, L = p->L;
+    H2W_HIP(hipSetDevice(p->device));
+    std::vector<uint64_t> head(pl.queries, 0);                 // the words before the per-query blocks
+    // ---- LDE: lde[poly][j] = f(7 w^bitrev(j))
+    H2W_HIP(hipEventRecord(p->ev[0], s));
+    hipLaunchKernelGGL(k_scale_pad, dim3(blocks(L, 256), (unsigned)p->np), dim3(256), 0, s, coeffs_dev, N, (uint64_t)7, L, p->lde);
+    ntt_dif(p, p->lde, lb, p->np, s);
+    H2W_HIP(hipEventRecord(p->ev[1], s));
+    // ---- Merkle commitments of the oracles
+    std::vector<H4> caps((size_t)no * cs);
+    for (int o = 0; o < no; o++) {
+        hipLaunchKernelGGL(k_leaves_initial, dim3(blocks(L, 64)), dim3(64), 0, s, p->dk, mode, p->lde + (uint64_t)p->poly0[o] * L, d.oracle_polys[o], L, p->tree[o]);
+        build_tree(p, p->tree[o], lb, s);
+        H2W_HIP(hipMemcpyAsync(caps.data() + (size_t)o * cs, p->tree[o] + level_off(lb, lb - capb), (size_t)cs * sizeof(H4), hipMemcpyDeviceToHost, s));
+    }
+    H2W_HIP(hipEventRecord(p->ev[2], s));
+    H2W_HIP(hipStreamSynchronize(s));
+    const int o_trace = 0, o_perm = sh.n_perm_z > 0 ? 1 : -1, o_quot = no - 1;
+    memcpy(&head[pl.trace_cap], &caps[(size_t)o_trace * cs], (size_t)cs * 32);
+    memcpy(&head[pl.quotient_cap], &caps[(size_t)o_quot * cs], (size_t)cs * 32);
+    if (o_perm >= 0) memcpy(&head[pl.perm_cap], &caps[(size_t)o_perm * cs], (size_t)cs * 32);
+    // ---- transcript up to zeta (challenger/mod.rs:168-222 in stark/mod.rs order)
+    HostChallenger ch(&p->hk.k);
+    for (int i = 0; i < cs; i++) ch.observe_hash(mode, caps[(size_t)o_trace * cs + i]);
+    if (o_perm >= 0) {
+        for (int set = 0; set < sh.perm_batch_size; set++) for (int i = 0; i < sh.num_challenges; i++) { ch.challenge(); ch.challenge(); }
+        for (int i = 0; i < cs; i++) ch.observe_hash(mode, caps[(size_t)o_perm * cs + i]);
+    }
+    for (int i = 0; i < sh.num_challenges; i++) ch.challenge();
+    for (int i = 0; i < cs; i++) ch.observe_hash(mode, caps[(size_t)o_quot * cs + i]);
+    const gle_t zeta = ch.ext_challenge(), gzeta = gle_mul(gle_of(gl_primitive_root_of_unity(sh.degree_bits)), zeta);
+    // ---- openings: batch 0 = every polynomial at zeta, batch 1 = trace and permutation Zs at g zeta
+    const int nz = p->np, nzn = p->np - d.oracle_polys[o_quot], eb = p->eval_blocks;
+    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)eb, (unsigned)nz), dim3(256), 0, s, coeffs_dev, N, zeta, p->partial);
+    if (nzn > 0) hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)eb, (unsigned)nzn), dim3(256), 0, s, coeffs_dev, N, gzeta, p->partial + (size_t)nz * eb);
+    std::vector<gle_t> part((size_t)(nz + nzn) * eb);
+    H2W_HIP(hipMemcpyAsync(part.data(), p->partial, part.size() * sizeof(gle_t), hipMemcpyDeviceToHost, s));
+    H2W_HIP(hipStreamSynchronize(s));
+    gle_t open[2][MAX_BATCH_POLYS];
+    for (int i = 0; i < nz + nzn; i++) { gle_t a = gle_of(0); for (int b = 0; b < eb; b++) a = gle_add(a, part[(size_t)i * eb + b]); if (i < nz) open[0][i] = a; else open[1][i - nz] = a; }
+    for (int i = 0; i < nz; i++) ch.observe_ext(open[0][i]);
+    for (int i = 0; i < nzn; i++) ch.observe_ext(open[1][i]);
+    const gle_t alpha = ch.ext_challenge();
+    {   // local_values, next_values, permutation_zs, permutation_zs_next, quotient_polys (witness/mod.rs:236-266 order)
+        uint64_t *w = &head[pl.openings]; const int nc = sh.n_cols, npz = sh.n_perm_z, nq = sh.n_quotient;
+        for (int i = 0; i < nc; i++) { *w++ = open[0][i].c[0]; *w++ = open[0][i].c[1]; }
+        for (int i = 0; i < nc; i++) { *w++ = open[1][i].c[0]; *w++ = open[1][i].c[1]; }
+        for (int i = 0; i < npz; i++) { *w++ = open[0][nc + i].c[0]; *w++ = open[0][nc + i].c[1]; }
+        for (int i = 0; i < npz; i++) { *w++ = open[1][nc + i].c[0]; *w++ = open[1][nc + i].c[1]; }
+        for (int i = 0; i < nq; i++) { *w++ = open[0][nc + npz + i].c[0]; *w++ = open[0][nc + npz + i].c[1]; }
+    }
+    // ---- F = (G_0 - G_0(zeta)) / (X - zeta) * alpha^{n_1} + (G_1 - G_1(g zeta)) / (X - g zeta)
+    gle_t *F = p->Fa, *Fo = p->Fb;
+    H2W_HIP(hipMemsetAsync(F, 0, L * sizeof(gle_t), s));
+    for (int b = 0; b < 2; b++) {
+        const int nb = b == 0 ? nz : nzn; if (nb == 0) continue;
+        QuotArgs A; A.coef = coeffs_dev; A.N = N; A.npoly = nb; A.z = b == 0 ? zeta : gzeta; A.zinv = gle_inv(A.z);
+        gle_t ap = gle_of(1); A.gz = gle_of(0);
+        for (int i = 0; i < nb; i++) { A.ap[i] = ap; A.gz = gle_add(A.gz, gle_mul(ap, open[b][i])); ap = gle_mul(ap, alpha); }
+        A.an = ap;
+        hipLaunchKernelGGL(k_quot_terms, dim3((unsigned)p->scan_blocks), dim3(256), 0, s, A, p->T, p->totals);
+        hipLaunchKernelGGL(k_suffix_totals, dim3(1), dim3(64), 0, s, p->totals, p->carry, p->scan_blocks);
+        hipLaunchKernelGGL(k_quot_finish, dim3((unsigned)p->scan_blocks), dim3(256), 0, s, A, p->T, p->carry, F);
+    }
+    H2W_HIP(hipEventRecord(p->ev[3], s));
+    // ---- commit phase
+    uint64_t shift = 7; int cur = lb;
+    std::vector<H4> fcap((size_t)cs);
+    for (int st = 0; st < d.n_steps; st++) {
+        const int ab = d.arity[st]; const uint64_t n = 1ull << cur, nl = n >> ab;
+        hipLaunchKernelGGL(k_split_scale, dim3(blocks(n, 256)), dim3(256), 0, s, F, n, shift, p->fv[st]);
+        ntt_dif(p, p->fv[st], cur, 2, s);
+        hipLaunchKernelGGL(k_leaves_fri, dim3(blocks(nl, 64)), dim3(64), 0, s, p->dk, mode, p->fv[st], p->fv[st] + n, ab, nl, p->ftree[st]);
+        build_tree(p, p->ftree[st], cur - ab, s);
+        H2W_HIP(hipMemcpyAsync(fcap.data(), p->ftree[st] + level_off(cur - ab, cur - ab - capb), (size_t)cs * sizeof(H4), hipMemcpyDeviceToHost, s));
+        H2W_HIP(hipStreamSynchronize(s));
+        memcpy(&head[pl.commit_caps + (uint64_t)st * cs * 4], fcap.data(), (size_t)cs * 32);
+        for (int i = 0; i < cs; i++) ch.observe_hash(mode, fcap[i]);
+        const gle_t beta = ch.ext_challenge();
+        hipLaunchKernelGGL(k_fold, dim3(blocks(nl, 256)), dim3(256), 0, s, F, Fo, nl, ab, beta);
+        gle_t *t = F; F = Fo; Fo = t;
+        shift = gl_exp(shift, 1ull << ab); cur -= ab;
+    }
+    const int fl = d.final_poly_len;
+    std::vector<gle_t> fin((size_t)fl);
+    H2W_HIP(hipMemcpyAsync(fin.data(), F, (size_t)fl * sizeof(gle_t), hipMemcpyDeviceToHost, s));
+    H2W_HIP(hipEventRecord(p->ev[4], s));
+    H2W_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < fl; i++) { head[pl.final_poly + 2 * i] = fin[i].c[0]; head[pl.final_poly + 2 * i + 1] = fin[i].c[1]; ch.observe_ext(fin[i]); }
+    // ---- proof of work: absorb the complete rate blocks of the pending inputs once, search the witness on the device
+    PowArgs PA; PA.pow_bits = sh.pow_bits; PA.ntail = (int)(ch.in.size() % SPONGE_RATE);
+    {
+        uint64_t st[12]; memcpy(st, ch.state, sizeof(st));
+        const size_t full = ch.in.size() - (size_t)PA.ntail;
+        for (size_t off = 0; off < full; off += SPONGE_RATE) { memcpy(st, ch.in.data() + off, SPONGE_RATE * 8); gl_permute(&p->hk.k, st); }
+        memcpy(PA.state, st, sizeof(st));
+        for (int i = 0; i < SPONGE_RATE; i++) PA.tail[i] = i < PA.ntail ? ch.in[full + i] : 0;
+    }
+    unsigned long long pow_witness = ~0ull;
+    for (uint64_t first = 0; pow_witness == ~0ull; first += 1ull << 18) {
+        if (first >> 40) { set_error("h2w_prove_fri: no proof-of-work witness found"); return -1; }
+        H2W_HIP(hipMemcpyAsync(p->best, &pow_witness, 8, hipMemcpyHostToDevice, s));
+        PA.first = first;
+        hipLaunchKernelGGL(k_pow, dim3(1u << 12), dim3(64), 0, s, p->dk, PA, p->best);
+        H2W_HIP(hipMemcpyAsync(&pow_witness, p->best, 8, hipMemcpyDeviceToHost, s));
+        H2W_HIP(hipStreamSynchronize(s));
+    }
+    H2W_HIP(hipEventRecord(p->ev[5], s));
+    head[pl.pow_witness] = pow_witness;
+    ch.observe(pow_witness); (void)ch.challenge();
+    // ---- query openings
+    std::vector<uint64_t> xs((size_t)sh.num_queries);
+    for (int q = 0; q < sh.num_queries; q++) xs[q] = ch.challenge() & (L - 1);
+    H2W_HIP(hipMemcpyAsync(p->x_index, xs.data(), xs.size() * 8, hipMemcpyHostToDevice, s));
+    GatherArgs G; G.lde = p->lde; G.L = L; G.lb = lb; G.capb = capb; G.no = no;
+    for (int o = 0; o < 3; o++) { G.npoly[o] = o < no ? d.oracle_polys[o] : 0; G.poly0[o] = p->poly0[o]; G.tree[o] = p->tree[o]; G.init_off[o] = pl.init_off[o]; }
+    G.n_steps = d.n_steps;
+    { uint64_t n = L; for (int st = 0; st < MAX_STEPS; st++) { G.ab[st] = st < d.n_steps ? d.arity[st] : 0; G.fv[st] = p->fv[st]; G.fn[st] = n; G.ftree[st] = p->ftree[st]; G.step_off[st] = pl.step_off[st]; if (st < d.n_steps) n >>= d.arity[st]; } }
+    G.proof = proof_dev; G.q_base = pl.queries; G.q_words = pl.query_words; G.x_index = p->x_index;
+    if (sh.num_queries > 0) hipLaunchKernelGGL(k_gather, dim3((unsigned)sh.num_queries), dim3(64), 0, s, G);
+    H2W_HIP(hipMemcpyAsync(proof_dev, head.data(), head.size() * 8, hipMemcpyHostToDevice, s));
+    if (sh.n_pis > 0) H2W_HIP(hipMemcpyAsync(proof_dev + pl.pis, public_inputs, (size_t)sh.n_pis * 8, hipMemcpyHostToDevice, s));
+    H2W_HIP(hipEventRecord(p->ev[6], s));
+    H2W_HIP(hipStreamSynchronize(s));
+    H2W_HIP(hipGetLastError());
+    for (int i = 0; i < 6; i++) { float t = 0; H2W_HIP(hipEventElapsedTime(&t, p->ev[i], p->ev[i + 1])); p->ms[i] = t; }
+    p->ms[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return 0;
+}
+int h2w_prover_timing(h2w_prover *p, float ms[7]) {
+    if (!p || !ms) { set_error("h2w_prover_timing: null argument"); return -1; }
+    for (int i = 0; i < 7; i++) ms[i] = p->ms[i];
+    return 0;
+}
+
+}  // extern "C"

@@ -254,6 +254,27 @@ int h2w_plan_last_timing(h2w_plan *, float ms[5]);
 /* Advice cells per proof written by the expansion kernel (the rest are written directly by the value kernels). */
 uint64_t h2w_plan_num_record_cells(const h2w_plan *);
 
+/* ------------------------------------------------------------------ the step BEFORE the path
+ * Synthetic VALID FRI instances generated on the GPU (SURVEY 8(d) variant (A)): low-degree extension (Goldilocks NTT on the coset
+ * 7<w>), Merkle commitments with the selected hash, the starky / plonky2 Fiat-Shamir transcript (stark/mod.rs:167-222 order, as
+ * ChallengerChip replays it: challenger/mod.rs:168-222), openings at zeta and g*zeta, the alpha-batched quotient, the FRI commit
+ * phase (arity 2^arity_bits coefficient folding), proof-of-work grinding and the query openings - written in the flat proof layout
+ * h2w_fri_witness_batch consumes, so proofs never visit the host.  The reference obtains such proofs from starky's
+ * prover (stark/mod.rs:405-426, test_util/fibonacci_stark.rs); as there, the committed polynomials are inputs: the STARK constraint
+ * identity is not part of the verifier gadget (stark/mod.rs:243-321 is commented out), any polynomials of degree < 2^degree_bits do.
+ * The serial sponge runs on the host between device phases (a few dozen permutations per proof). */
+typedef struct h2w_prover h2w_prover;
+h2w_prover *h2w_prover_new(const h2w_shape_t *, const h2w_poseidon_consts_t *, int device_id);
+void        h2w_prover_free(h2w_prover *);
+uint64_t    h2w_prover_num_polys(const h2w_prover *);      /* n_cols + n_perm_z + n_quotient */
+uint64_t    h2w_prover_proof_words(const h2w_prover *);    /* = h2w_plan_proof_words of the same shape */
+/* coeffs_dev: [num_polys][2^degree_bits] canonical Goldilocks coefficients (trace columns, permutation Zs, quotient polynomials), device.
+ * public_inputs: n_pis words, host.  proof_dev: proof_words u64, device.  Synchronises `stream` several times (transcript). */
+int h2w_prove_fri(h2w_prover *, const uint64_t *coeffs_dev, const uint64_t *public_inputs, uint64_t *proof_dev, void *stream);
+/* ms[0] = LDE (NTTs), ms[1] = Merkle commitments of the oracles, ms[2] = openings + batched quotient, ms[3] = FRI commit phase,
+ * ms[4] = proof of work, ms[5] = query openings, ms[6] = whole call (wall clock incl. the host transcript) of the last h2w_prove_fri */
+int h2w_prover_timing(h2w_prover *, float ms[7]);
+
 #ifdef __cplusplus
 }
 #endif

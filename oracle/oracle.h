@@ -102,6 +102,8 @@ void orc_synth_proof(const oshape_t *, uint64_t seed, uint64_t *words);
 /* a VALID FRI instance of the shape (native value-domain prover following plonky2's prover conventions, prover.inc);
  * on it the restated MockProver must report semantic_failed == 0.  Small shapes only (lde_bits <= 20). */
 int orc_prove_fri(const oshape_t *, const oconsts_t *, uint64_t seed, uint64_t *words);
+size_t orc_prove_fri_inputs(const oshape_t *, uint64_t seed, uint64_t *coefs, uint64_t *pis);   /* returns the number of coefficient words */
+int orc_prove_fri_coef(const oshape_t *, const oconsts_t *, const uint64_t *coefs, const uint64_t *pis, uint64_t *words);
 /* native (no-cell) twins of the hash gadgets, for cross-checks */
 void orc_nv_gl_permute(const oconsts_t *, uint64_t st[12]);
 void orc_nv_bn_permute(const oconsts_t *, ofr_t st[4]);

@@ -110,6 +110,10 @@ def lib():
     L.orc_layout_lookup_columns.restype = C.c_uint64; L.orc_layout_lookup_columns.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orc_prove_fri.restype = C.c_int
     L.orc_prove_fri.argtypes = [C.POINTER(Shape), C.POINTER(Consts), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_prove_fri_inputs.restype = C.c_size_t
+    L.orc_prove_fri_inputs.argtypes = [C.POINTER(Shape), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.orc_prove_fri_coef.restype = C.c_int
+    L.orc_prove_fri_coef.argtypes = [C.POINTER(Shape), C.POINTER(Consts), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.orc_nv_gl_permute.argtypes = [C.POINTER(Consts), C.POINTER(C.c_uint64)]
     L.orc_nv_bn_permute.argtypes = [C.POINTER(Consts), C.POINTER(Fr)]
     L.orc_nv_hash_or_noop.argtypes = [C.POINTER(Consts), C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
@@ -294,6 +298,22 @@ def prove_fri(shape, consts, seed):
     rc = lib().orc_prove_fri(C.byref(shape), C.byref(consts), seed, buf)
     if rc != 0:
         raise RuntimeError("orc_prove_fri: unsupported shape")
+    return buf
+
+
+def prove_fri_inputs(shape, seed):
+    """The committed polynomials' coefficients ([polynomial][2^degree_bits]) and public inputs orc_prove_fri(seed) uses."""
+    n = lib().orc_prove_fri_inputs(C.byref(shape), seed, None, None)
+    coefs = (C.c_uint64 * n)(); pis = (C.c_uint64 * max(shape.n_pis, 1))()
+    lib().orc_prove_fri_inputs(C.byref(shape), seed, coefs, pis)
+    return coefs, pis
+
+
+def prove_fri_coef(shape, consts, coefs, pis):
+    n = lib().orc_proof_words(C.byref(shape))
+    buf = (C.c_uint64 * n)()
+    if lib().orc_prove_fri_coef(C.byref(shape), C.byref(consts), coefs, pis, buf) != 0:
+        raise RuntimeError("orc_prove_fri_coef: unsupported shape")
     return buf
 
 
