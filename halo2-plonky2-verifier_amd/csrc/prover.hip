@@ -264,9 +264,12 @@ __global__ void k_leaves_fri(const ProverConsts *K, int mode, const uint64_t *v0
     for (int t = 0; t < MAX_ARITY; t++) { buf[2 * t] = t < ar ? v0[(j << ab) + t] : 0; buf[2 * t + 1] = t < ar ? v1[(j << ab) + t] : 0; }
     leaves[j] = hash_or_noop<2 * MAX_ARITY>(K, mode, buf, 2 * ar);
 }
-__global__ void k_tree_level(const ProverConsts *K, int mode, const H4 *in, H4 *out, uint64_t m) {
+// one level of gridDim.y trees that sit tree_stride hashes apart (the initial oracles' trees have the same shape: their
+// levels are built together, so the latency-bound upper levels are paid once, not once per oracle)
+__global__ void k_tree_level(const ProverConsts *K, int mode, const H4 *in, H4 *out, uint64_t m, uint64_t tree_stride) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    in += blockIdx.y * tree_stride; out += blockIdx.y * tree_stride;
     out[i] = two_to_one(K, mode, in[2 * i], in[2 * i + 1]);
 }
 // partial[p][block] = sum over the block's coefficients c_i x^i (blocked Horner, then a block reduction)
@@ -449,10 +452,10 @@ void ntt_dif(const h2w_prover *p, uint64_t *a, int bits, int count, hipStream_t 
     if (tb >= 1) hipLaunchKernelGGL(k_dif_local, dim3((unsigned)(n >> tb), (unsigned)count), dim3(256), 0, s, a, n, tb, p->tw, p->d.lde_bits);
 }
 // all levels above the leaves up to the cap (level bits - capb)
-void build_tree(const h2w_prover *p, H4 *base, int bits, hipStream_t s) {
+void build_trees(const h2w_prover *p, H4 *base, int bits, int count, uint64_t tree_stride, hipStream_t s) {
     for (int l = 1; l <= bits - p->shape.cap_height; l++) {
         const uint64_t m = 1ull << (bits - l);
-        hipLaunchKernelGGL(k_tree_level, dim3(blocks(m, 64)), dim3(64), 0, s, p->dk, p->shape.hash_mode, base + level_off(bits, l - 1), base + level_off(bits, l), m);
+        hipLaunchKernelGGL(k_tree_level, dim3(blocks(m, 64), (unsigned)count), dim3(64), 0, s, p->dk, p->shape.hash_mode, base + level_off(bits, l - 1), base + level_off(bits, l), m, tree_stride);
     }
 }
 }  // namespace
@@ -483,7 +486,8 @@ h2w_prover *h2w_prover_new(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     dm((void **)&p->dk, sizeof(ProverConsts));
     dm((void **)&p->tw, (p->L / 2 ? p->L / 2 : 1) * 8);
     dm((void **)&p->lde, (size_t)p->np * p->L * 8);
-    for (int o = 0; o < d.n_oracles; o++) dm((void **)&p->tree[o], 2 * p->L * sizeof(H4));
+    dm((void **)&p->tree[0], (size_t)d.n_oracles * 2 * p->L * sizeof(H4));
+    for (int o = 1; o < d.n_oracles && ok; o++) p->tree[o] = p->tree[0] + (size_t)o * 2 * p->L;
     dm((void **)&p->Fa, p->L * sizeof(gle_t)); dm((void **)&p->Fb, p->L * sizeof(gle_t)); dm((void **)&p->T, p->N * sizeof(gle_t));
     p->scan_blocks = (int)blocks(p->N, SCAN_TILE); p->eval_blocks = (int)blocks(p->N, 256 * EVAL_PER_THREAD);
     dm((void **)&p->totals, p->scan_blocks * sizeof(gle_t)); dm((void **)&p->carry, p->scan_blocks * sizeof(gle_t));
@@ -500,7 +504,7 @@ void h2w_prover_free(h2w_prover *p) {
     if (!p) return;
     hipFree(p->dk); hipFree(p->tw); hipFree(p->lde); hipFree(p->Fa); hipFree(p->Fb); hipFree(p->T); hipFree(p->totals); hipFree(p->carry);
     hipFree(p->partial); hipFree(p->x_index); hipFree(p->best);
-    for (int o = 0; o < 3; o++) hipFree(p->tree[o]);
+    hipFree(p->tree[0]);
     for (int st = 0; st < MAX_STEPS; st++) { hipFree(p->fv[st]); hipFree(p->ftree[st]); }
     for (int i = 0; i < 8; i++) if (p->ev[i]) hipEventDestroy(p->ev[i]);
     delete p;
@@ -526,7 +530,9 @@ int h2w_prove_fri(h2w_prover *p, const uint64_t *coeffs_dev, const uint64_t *pub
     std::vector<H4> caps((size_t)no * cs);
     for (int o = 0; o < no; o++) {
         hipLaunchKernelGGL(k_leaves_initial, dim3(blocks(L, 64)), dim3(64), 0, s, p->dk, mode, p->lde + (uint64_t)p->poly0[o] * L, d.oracle_polys[o], L, p->tree[o]);
-        build_tree(p, p->tree[o], lb, s);
+    }
+    build_trees(p, p->tree[0], lb, no, 2 * L, s);
+    for (int o = 0; o < no; o++) {
         H2W_HIP(hipMemcpyAsync(caps.data() + (size_t)o * cs, p->tree[o] + level_off(lb, lb - capb), (size_t)cs * sizeof(H4), hipMemcpyDeviceToHost, s));
     }
     H2W_HIP(hipEventRecord(p->ev[2], s));
@@ -587,7 +593,7 @@ int h2w_prove_fri(h2w_prover *p, const uint64_t *coeffs_dev, const uint64_t *pub
         hipLaunchKernelGGL(k_split_scale, dim3(blocks(n, 256)), dim3(256), 0, s, F, n, shift, p->fv[st]);
         ntt_dif(p, p->fv[st], cur, 2, s);
         hipLaunchKernelGGL(k_leaves_fri, dim3(blocks(nl, 64)), dim3(64), 0, s, p->dk, mode, p->fv[st], p->fv[st] + n, ab, nl, p->ftree[st]);
-        build_tree(p, p->ftree[st], cur - ab, s);
+        build_trees(p, p->ftree[st], cur - ab, 1, 0, s);
         H2W_HIP(hipMemcpyAsync(fcap.data(), p->ftree[st] + level_off(cur - ab, cur - ab - capb), (size_t)cs * sizeof(H4), hipMemcpyDeviceToHost, s));
         H2W_HIP(hipStreamSynchronize(s));
         memcpy(&head[pl.commit_caps + (uint64_t)st * cs * 4], fcap.data(), (size_t)cs * 32);

@@ -83,3 +83,40 @@ def test_gpu_proof_into_gpu_witness(h2w, h2w_api, oracle, published, mode):
     assert mp["bad"] == 0 and mp["semantic_failed"] == 0, mp            # Merkle roots, fold consistency, final polynomial, PoW
     assert advice.cpu().numpy().tobytes() == ctx.advice_bytes()
     ctx.close(); plan.close()
+
+
+@pytest.mark.parametrize("case", ["cfg2_gl", "cfg2_bn254", "cfg3_gl"])
+def test_full_size_proofs_equal_the_oracle_provers_digest(h2w, h2w_api, oracle, published, case):
+    """BASELINE.json's full sizes: the oracle prover needs 15-90 s per proof there, so its output is committed as a sha256
+    (tests/golden/prover_digests.json, made by tools/make_golden_prover.py from the same seeded inputs)."""
+    import hashlib, json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prover_digests.json")))[case]
+    ko, kh = published
+    sh = h2w.fibonacci_shape(gold["degree_bits"], gold["queries"], rate_bits=gold["rate_bits"], hash_mode=gold["hash_mode"])
+    osh = oracle.fibonacci_shape(gold["degree_bits"], gold["queries"], rate_bits=gold["rate_bits"], hash_mode=gold["hash_mode"])
+    _, _, d_proof, _ = gpu_prove(h2w, h2w_api, oracle, kh, sh, osh, gold["seed"])
+    assert d_proof.numel() == gold["proof_words"]
+    assert hashlib.sha256(d_proof.cpu().numpy().tobytes()).hexdigest() == gold["sha256"]
+
+
+def test_config3_bn254_proof_is_a_valid_fri_instance(h2w, h2w_api, oracle, published):
+    """BASELINE.json configs[2] with PoseidonBN254 caps (the oracle prover would need ~12 minutes): the GPU-generated proof is
+    accepted by the restated verifier - every gate, lookup and copy constraint of the 28.6 M-cell witness holds, i.e. all Merkle
+    paths verify against the caps, every fold step is consistent, the final polynomial matches and the PoW response has its
+    leading zeros - and the GPU witness of it equals the oracle's."""
+    import torch
+    ko, kh = published
+    sh = h2w.fibonacci_shape(20, 28, rate_bits=1, hash_mode=1); osh = oracle.fibonacci_shape(20, 28, rate_bits=1, hash_mode=1)
+    _, _, d_proof, _ = gpu_prove(h2w, h2w_api, oracle, kh, sh, osh, 0xF1B00003)
+    plan = h2w_api.Plan(sh, kh)
+    advice = torch.zeros(plan.num_cells * 32, dtype=torch.uint8, device="cuda"); ws = torch.zeros(plan.workspace_bytes(1), dtype=torch.uint8, device="cuda")
+    plan.run(d_proof.data_ptr(), 1, advice.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert plan.status(ws.data_ptr(), 1) == [0] and plan.check_constraints(advice.data_ptr(), 1) == (0, 0)
+    ctx = oracle.Ctx(21, witness_gen_only=False)
+    words = (C.c_uint64 * plan.proof_words).from_buffer_copy(d_proof.cpu().numpy().tobytes())
+    assert oracle.verify_stark(ctx, osh, ko, words) == 0
+    mp = ctx.mock_prover()
+    assert mp["bad"] == 0 and mp["semantic_failed"] == 0, mp
+    assert advice.cpu().numpy().tobytes() == ctx.advice_bytes()
+    ctx.close(); plan.close()
