@@ -161,6 +161,7 @@ SYMBOLS = {
     "h2w_prover_num_polys": (C.c_uint64, [_vp]),
     "h2w_prover_proof_words": (C.c_uint64, [_vp]),
     "h2w_prove_fri": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), _vp, _vp]),
+    "h2w_prove_fri_batch": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), _vp, C.c_uint64, _vp]),
     "h2w_prover_timing": (C.c_int, [_vp, C.POINTER(C.c_float)]),
 }
 

@@ -346,6 +346,11 @@ class Prover:
         pis = (C.c_uint64 * max(len(public_inputs), 1))(*public_inputs)
         _ck(self.L.h2w_prove_fri(self.p, coeffs_ptr, pis, proof_ptr, stream), "h2w_prove_fri")
 
+    def prove_batch(self, coeffs_ptr, public_inputs, proofs_ptr, n, stream=0):
+        """n proofs in lockstep: coeffs [n][num_polys][2^degree_bits] (device), public_inputs flat [n][n_pis], proofs [n][proof_words] (device)."""
+        pis = (C.c_uint64 * max(len(public_inputs), 1))(*public_inputs)
+        _ck(self.L.h2w_prove_fri_batch(self.p, coeffs_ptr, pis, proofs_ptr, n, stream), "h2w_prove_fri_batch")
+
     def timing(self):
         ms = (C.c_float * 7)()
         _ck(self.L.h2w_prover_timing(self.p, ms), "h2w_prover_timing")

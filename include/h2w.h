@@ -271,8 +271,13 @@ uint64_t    h2w_prover_proof_words(const h2w_prover *);    /* = h2w_plan_proof_w
 /* coeffs_dev: [num_polys][2^degree_bits] canonical Goldilocks coefficients (trace columns, permutation Zs, quotient polynomials), device.
  * public_inputs: n_pis words, host.  proof_dev: proof_words u64, device.  Synchronises `stream` several times (transcript). */
 int h2w_prove_fri(h2w_prover *, const uint64_t *coeffs_dev, const uint64_t *public_inputs, uint64_t *proof_dev, void *stream);
+/* n_proofs (<= 2048) instances in lockstep: coeffs_dev [n_proofs][num_polys][2^degree_bits], public_inputs [n_proofs][n_pis] (host),
+ * proofs_dev [n_proofs][proof_words].  Every kernel covers the whole batch and the host transcript serves all proofs at each of its
+ * round trips, so the latency-bound pieces (upper tree levels, small fold steps) are paid once per batch.  Device scratch is
+ * (re)allocated inside the handle for the largest batch seen (cfg 3: about 0.65 GB per proof). */
+int h2w_prove_fri_batch(h2w_prover *, const uint64_t *coeffs_dev, const uint64_t *public_inputs, uint64_t *proofs_dev, uint64_t n_proofs, void *stream);
 /* ms[0] = LDE (NTTs), ms[1] = Merkle commitments of the oracles, ms[2] = openings + batched quotient, ms[3] = FRI commit phase,
- * ms[4] = proof of work, ms[5] = query openings, ms[6] = whole call (wall clock incl. the host transcript) of the last h2w_prove_fri */
+ * ms[4] = proof of work, ms[5] = query openings, ms[6] = whole call (wall clock incl. the host transcript) of the last h2w_prove_fri / h2w_prove_fri_batch */
 int h2w_prover_timing(h2w_prover *, float ms[7]);
 
 #ifdef __cplusplus

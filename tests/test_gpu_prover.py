@@ -120,3 +120,26 @@ def test_config3_bn254_proof_is_a_valid_fri_instance(h2w, h2w_api, oracle, publi
     assert mp["bad"] == 0 and mp["semantic_failed"] == 0, mp
     assert advice.cpu().numpy().tobytes() == ctx.advice_bytes()
     ctx.close(); plan.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_lockstep_batch_equals_proof_by_proof(h2w, h2w_api, oracle, published, mode):
+    """h2w_prove_fri_batch: five instances with different polynomials through every kernel together; each proof equals the
+    oracle prover's for its own inputs (two fold steps, so the per-proof betas / PoW states / query indices all differ)."""
+    import numpy as np
+    import torch
+    ko, kh = published
+    sh = h2w.fibonacci_shape(13, 4, rate_bits=1, cap_height=3, hash_mode=mode); osh = oracle.fibonacci_shape(13, 4, rate_bits=1, cap_height=3, hash_mode=mode)
+    seeds = [900 + i for i in range(5)]
+    ins = [oracle.prove_fri_inputs(osh, sd) for sd in seeds]
+    pr = h2w_api.Prover(sh, kh)
+    coefs = torch.from_numpy(np.concatenate([np.frombuffer(c, dtype=np.int64) for c, _ in ins])).cuda()
+    pis = [int(x) for _, p_ in ins for x in list(p_)[:sh.n_pis]]
+    proofs = torch.zeros(len(seeds) * pr.proof_words, dtype=torch.int64, device="cuda")
+    pr.prove_batch(coefs.data_ptr(), pis, proofs.data_ptr(), len(seeds), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = proofs.cpu().numpy().view(np.uint64).reshape(len(seeds), pr.proof_words)
+    for i, (c, p_) in enumerate(ins):
+        want = np.frombuffer(oracle.prove_fri_coef(osh, ko, c, p_), dtype=np.uint64)
+        assert (got[i] == want).all(), f"proof {i} of the batch differs"
+    pr.close()
