@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--lookup-bits", type=int, default=21)
     ap.add_argument("--streams", type=int, default=0, help="batches in flight, each on its own HIP stream with its own advice/workspace buffers (0 = auto)")
     ap.add_argument("--calib", type=int, default=5, help="isolated single-stream launches after the timed region for the roofline numbers")
+    ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment: CU-masked streams, value strands on the first N CUs, expansion on the rest")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
@@ -121,16 +122,34 @@ def main():
 
     # ---- inputs: rank 0 synthesises all proofs, one RCCL broadcast moves the proof block
     words = plan.proof_words
-    host = torch.empty(total_proofs * words, dtype=torch.int64)
-    if rank == 0:      # uniform random proof words (witness generation does not branch on validity, SURVEY §8d variant (B)); < 2^60: see above
-        prng = np.random.default_rng(0xF1B00000)
-        host[:] = torch.from_numpy(prng.integers(0, 1 << 60, total_proofs * words, dtype=np.int64))
-    if args.backend == "gloo":                      # rehearsal: broadcast on the host, then upload
-        D.broadcast_proofs(host, src=0)
-        all_proofs = host.to(dev)
-    else:
-        all_proofs = host.to(dev)
+    if args.proofs == "valid" and args.backend != "gloo":
+        # valid FRI instances (SURVEY 8d variant (A)): random committed polynomials, proved on the ingest rank's GPU in lockstep batches;
+        # the proofs never visit the host.  Every distinct proof is used (no repetition inside a step).
+        all_proofs = torch.zeros(total_proofs * words, dtype=torch.int64, device=dev)
+        if rank == 0:
+            pr = api.Prover(shape, consts, local_rank)
+            assert pr.proof_words == words
+            gen = torch.Generator(device=dev); gen.manual_seed(0xF1B00000)
+            chunk = max(1, min(total_proofs, (8 << 21) >> (d + rb)))              # ~5 GB of prover scratch at a time
+            for first in range(0, total_proofs, chunk):
+                nb = min(chunk, total_proofs - first)
+                coefs = torch.randint(0, 1 << 62, (nb * pr.num_polys << d,), dtype=torch.int64, device=dev, generator=gen)   # < 2^62 < p: canonical
+                pr.prove_batch(coefs.data_ptr(), [1, 1, 2] * nb, all_proofs[first * words:].data_ptr(), nb, torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize(dev)
+            pr.close(); del coefs
+            torch.cuda.empty_cache()
         D.broadcast_proofs(all_proofs, src=0)       # the only collective (RCCL over xGMI): ingest rank -> all ranks
+    else:
+        host = torch.empty(total_proofs * words, dtype=torch.int64)
+        if rank == 0:      # uniform random proof words (witness generation does not branch on validity, SURVEY 8d variant (B)); every word < 2^60:
+            prng = np.random.default_rng(0xF1B00000)     # Goldilocks words canonical (< p), every 4-word hash a canonical Fr (< 2^252 < r)
+            host[:] = torch.from_numpy(prng.integers(0, 1 << 60, total_proofs * words, dtype=np.int64))
+        if args.backend == "gloo":                      # rehearsal: broadcast on the host, then upload
+            D.broadcast_proofs(host, src=0)
+            all_proofs = host.to(dev)
+        else:
+            all_proofs = host.to(dev)
+            D.broadcast_proofs(all_proofs, src=0)       # the only collective (RCCL over xGMI): ingest rank -> all ranks
     lo, hi = D.shard_range(total_proofs, world, rank)
     assert hi - lo == B
     my_proofs = all_proofs[lo * words:hi * words]
@@ -222,6 +241,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {desc}, {'PoseidonBN254' if hash_mode else 'Goldilocks-Poseidon'} Merkle, lookup_bits={args.lookup_bits}",
                        "proofs_per_gpu_per_step": B, "batches_in_flight": S, "cells_per_proof": plan.num_cells, "includes_witness_load_cells": True,
+                       "proofs": "valid FRI instances of random polynomials, generated on the GPU by the ingest rank (h2w_prove_fri_batch)" if args.proofs == "valid" and args.backend != "gloo" else "uniform random words of the proof's shape",
                        "parallelism": f"proof-sharded x{world}, no data-path collective"},
             "proofs_per_s": total_proofs * args.steps / elapsed,
             "advice_GBps": value * 32 / 1e9,
