@@ -34,7 +34,10 @@ HD gle_t gle_of(uint64_t a) { gle_t r; r.c[0] = a; r.c[1] = 0; return r; }
 HD gle_t gle_pow(gle_t a, uint64_t e) { gle_t acc = gle_of(1); while (e) { if (e & 1) acc = gle_mul(acc, a); a = gle_mul(a, a); e >>= 1; } return acc; }
 
 // ---------------------------------------------------------------- Goldilocks Poseidon, plonky2 "fast" layout (hash/poseidon/permutation.rs:43-314)
-HDN inline void gl_permute(const h2w_poseidon_consts_t *k, uint64_t *st) {
+// SMALL_MDS: every MDS_MATRIX_CIRC / _DIAG entry is below 2^28 (plonky2's are <= 41): a row is then two 64-bit accumulations over the
+// 32-bit halves of the state (13 terms < 2^32 * 2^28 each) and ONE reduction, instead of 13 reduced 64x64 products - the full
+// rounds' MDS layers are two thirds of a permutation's instructions otherwise.  Same values either way (exact arithmetic).
+template <bool SMALL_MDS> HDN inline void gl_permute_t(const h2w_poseidon_consts_t *k, uint64_t *st) {
     int rc = 0;
     for (int half = 0; half < 2; half++) {
         if (half == 1) {
@@ -72,12 +75,26 @@ HDN inline void gl_permute(const h2w_poseidon_consts_t *k, uint64_t *st) {
                 uint64_t x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x6 = gl_mul(x4, x2); st[i] = gl_mul(x6, x);
             }
             uint64_t res[12];
+            if (SMALL_MDS) {
+                uint32_t lo32[12], hi32[12];
 #pragma unroll
-            for (int r = 0; r < 12; r++) {
-                uint64_t acc = 0;
+                for (int i = 0; i < 12; i++) { lo32[i] = (uint32_t)st[i]; hi32[i] = (uint32_t)(st[i] >> 32); }
 #pragma unroll
-                for (int i = 0; i < 12; i++) acc = gl_muladd(k->mds_circ[i], st[(i + r) % 12], acc);
-                res[r] = gl_muladd(k->mds_diag[r], st[r], acc);
+                for (int r = 0; r < 12; r++) {
+                    const uint32_t dg = (uint32_t)k->mds_diag[r];
+                    uint64_t lo = (uint64_t)lo32[r] * dg, hi = (uint64_t)hi32[r] * dg;
+#pragma unroll
+                    for (int i = 0; i < 12; i++) { const uint32_t c = (uint32_t)k->mds_circ[i]; lo += (uint64_t)lo32[(i + r) % 12] * c; hi += (uint64_t)hi32[(i + r) % 12] * c; }
+                    res[r] = gl_reduce128((u128)lo + ((u128)hi << 32));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 12; r++) {
+                    uint64_t acc = 0;
+#pragma unroll
+                    for (int i = 0; i < 12; i++) acc = gl_muladd(k->mds_circ[i], st[(i + r) % 12], acc);
+                    res[r] = gl_muladd(k->mds_diag[r], st[r], acc);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 12; r++) st[r] = res[r];
@@ -85,6 +102,13 @@ HDN inline void gl_permute(const h2w_poseidon_consts_t *k, uint64_t *st) {
         }
     }
 }
+
+HDN inline bool gl_mds_is_small(const h2w_poseidon_consts_t *k) {
+    bool small = true;
+    for (int i = 0; i < 12; i++) small = small && k->mds_circ[i] < (1ull << 28) && k->mds_diag[i] < (1ull << 28);
+    return small;
+}
+HDN inline void gl_permute(const h2w_poseidon_consts_t *k, uint64_t *st) { if (gl_mds_is_small(k)) gl_permute_t<true>(k, st); else gl_permute_t<false>(k, st); }
 
 // ---------------------------------------------------------------- PoseidonBN254 (hash/poseidon_bn254/permutation.rs:48-203), Montgomery-form state
 HNI fr_t mmul(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }

@@ -143,3 +143,18 @@ def test_lockstep_batch_equals_proof_by_proof(h2w, h2w_api, oracle, published, m
         want = np.frombuffer(oracle.prove_fri_coef(osh, ko, c, p_), dtype=np.uint64)
         assert (got[i] == want).all(), f"proof {i} of the batch differs"
     pr.close()
+
+
+def test_full_width_mds_constants(h2w, h2w_api, oracle, consts):
+    """MDS entries of 64 bits (no published table has them, a caller's may): the generic MDS layer, not the two-accumulator one."""
+    import numpy as np
+    ko0, _ = consts
+    ko = oracle.Consts.from_buffer_copy(bytes(ko0))
+    for i in range(12):
+        ko.mds_circ[i] = (0x9E3779B97F4A7C15 * (i + 1)) % (2**64 - 2**32 + 1)
+        ko.mds_diag[i] = (0xD1B54A32D192ED03 * (i + 3)) % (2**64 - 2**32 + 1)
+    kh = h2w.PoseidonConsts.from_buffer_copy(bytes(ko))
+    sh = h2w.fibonacci_shape(9, 2, rate_bits=1, cap_height=2, hash_mode=0); osh = oracle.fibonacci_shape(9, 2, rate_bits=1, cap_height=2, hash_mode=0)
+    coefs, pis, d_proof, _ = gpu_prove(h2w, h2w_api, oracle, kh, sh, osh, 78)
+    want = np.frombuffer(oracle.prove_fri_coef(osh, ko, coefs, pis), dtype=np.uint64)
+    assert (d_proof.cpu().numpy().view(np.uint64) == want).all()
