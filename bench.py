@@ -237,7 +237,7 @@ def main():
     elapsed = D.max_over_ranks(elapsed, torch.device("cpu") if args.backend == "gloo" else dev)
     for i in range(S):
         status = plan.status(wss[i].data_ptr(), B, streams[i].cuda_stream)
-        assert status == [0] * B, f"device status {status}"
+        assert status == [0] * B or os.environ.get("H2W_DBG_SKIP_KERNELS") or os.environ.get("H2W_DBG_SKIP_ALT"), f"device status {status}"   # (the skip hooks exist in H2W_DEBUG_HOOKS builds only)
 
     # per-kernel timing from the HIP events the library records on the launch stream around every kernel group.
     # (a) over the timed region (batches overlap each other there, so these intervals include time-sharing);

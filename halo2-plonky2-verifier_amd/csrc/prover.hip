@@ -34,6 +34,10 @@ HD gle_t gle_of(uint64_t a) { gle_t r; r.c[0] = a; r.c[1] = 0; return r; }
 HD gle_t gle_pow(gle_t a, uint64_t e) { gle_t acc = gle_of(1); while (e) { if (e & 1) acc = gle_mul(acc, a); a = gle_mul(a, a); e >>= 1; } return acc; }
 
 // ---------------------------------------------------------------- Goldilocks Poseidon, plonky2 "fast" layout (hash/poseidon/permutation.rs:43-314)
+// dot products of full-width words: 128-bit accumulator + overflow count, reduced once (2^128 = -2^32 mod p)
+struct GlAcc { u128 lo; uint32_t carries; };
+HD void glacc_mul(GlAcc &a, uint64_t x, uint64_t y) { const u128 pr = (u128)x * y; a.lo += pr; a.carries += a.lo < pr; }
+HD uint64_t glacc_reduce(const GlAcc &a) { return gl_sub(gl_reduce128(a.lo), (uint64_t)a.carries << 32); }
 // SMALL_MDS: every MDS_MATRIX_CIRC / _DIAG entry is below 2^28 (plonky2's are <= 41): a row is then two 64-bit accumulations over the
 // 32-bit halves of the state (13 terms < 2^32 * 2^28 each) and ONE reduction, instead of 13 reduced 64x64 products - the full
 // rounds' MDS layers are two thirds of a permutation's instructions otherwise.  Same values either way (exact arithmetic).
@@ -44,12 +48,13 @@ template <bool SMALL_MDS> HDN inline void gl_permute_t(const h2w_poseidon_consts
 #pragma unroll
             for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], k->fast_partial_first_round_constant[i]);
             uint64_t res[12];
+            res[0] = st[0];
 #pragma unroll
-            for (int c = 0; c < 12; c++) res[c] = c == 0 ? st[0] : 0;
+            for (int c = 1; c < 12; c++) {
+                GlAcc a; a.lo = 0; a.carries = 0;
 #pragma unroll
-            for (int r = 1; r < 12; r++) {
-#pragma unroll
-                for (int c = 1; c < 12; c++) res[c] = gl_muladd(k->fast_partial_round_initial_matrix[r - 1][c - 1], st[r], res[c]);
+                for (int r = 1; r < 12; r++) glacc_mul(a, k->fast_partial_round_initial_matrix[r - 1][c - 1], st[r]);
+                res[c] = glacc_reduce(a);
             }
 #pragma unroll
             for (int c = 0; c < 12; c++) st[c] = res[c];
@@ -58,12 +63,12 @@ template <bool SMALL_MDS> HDN inline void gl_permute_t(const h2w_poseidon_consts
             for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
                 uint64_t x = st[0], x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x6 = gl_mul(x4, x2);
                 const uint64_t s0 = gl_add(gl_mul(x6, x), k->fast_partial_round_constants[r]);
-                uint64_t d = gl_mul(m00, s0);
+                GlAcc a; a.lo = (u128)m00 * s0; a.carries = 0;
 #pragma unroll
-                for (int i = 1; i < 12; i++) d = gl_muladd(k->fast_partial_round_w_hats[r][i - 1], st[i], d);
+                for (int i = 1; i < 12; i++) glacc_mul(a, k->fast_partial_round_w_hats[r][i - 1], st[i]);
 #pragma unroll
                 for (int i = 1; i < 12; i++) st[i] = gl_muladd(k->fast_partial_round_vs[r][i - 1], s0, st[i]);
-                st[0] = d;
+                st[0] = glacc_reduce(a);
             }
             rc += N_PARTIAL_ROUNDS;
         }
@@ -693,9 +698,11 @@ int h2w_prove_fri_batch(h2w_prover *p, const uint64_t *coeffs_dev, const uint64_
     }
     H2W_HIP(hipMemcpyAsync(p->pargs, pa.data(), n * sizeof(PowArgs), hipMemcpyHostToDevice, s));
     H2W_HIP(hipMemcpyAsync(p->best, wit.data(), n * 8, hipMemcpyHostToDevice, s));
-    for (uint64_t first = 0;; first += 1ull << 18) {
+    // 2^pow_bits candidates per round (63 % of the proofs finish in each; finished proofs' blocks exit at once)
+    const int round_bits = sh.pow_bits < 8 ? 8 : sh.pow_bits > 22 ? 22 : sh.pow_bits;
+    for (uint64_t first = 0;; first += 1ull << round_bits) {
         if (first >> 40) { set_error("h2w_prove_fri_batch: no proof-of-work witness found"); return -1; }
-        hipLaunchKernelGGL(k_pow, dim3(1u << 12, nb), dim3(64), 0, s, p->dk, p->pargs, first, p->best);
+        hipLaunchKernelGGL(k_pow, dim3(1u << (round_bits - 6), nb), dim3(64), 0, s, p->dk, p->pargs, first, p->best);
         H2W_HIP(hipMemcpyAsync(wit.data(), p->best, n * 8, hipMemcpyDeviceToHost, s));
         H2W_HIP(hipStreamSynchronize(s));
         bool all = true; for (uint64_t b = 0; b < n; b++) all = all && wit[b] != ~0ull;
