@@ -219,8 +219,8 @@ typedef CoopSinkT<false> CoopSink;
 // with s_waitcnt vmcnt(0), i.e. waits for all cell stores in flight.
 __device__ __attribute__((noinline)) fr_t mont_call(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }
 
-// per-quad LDS staging regions of the BN254 quad emitter (QuadSink::stage / flush): 16 quads x QST cells = 16 KB per wavefront,
-// small enough for two wavefronts per SIMD (one computes while the other drains its stores)
+// per-quad LDS staging regions of the BN254 quad emitter (QuadSink::stage / flush): 16 quads x QST cells x 32 B per wavefront
+// (QST 64: 32 KB, five wavefronts per CU by LDS; QST 32: 16 KB, and the 4-lane layers are staged in two passes)
 #ifndef H2W_QST
 #define H2W_QST 64
 #endif
@@ -231,7 +231,8 @@ __device__ __attribute__((noinline)) fr_t mont_call(fr_t a, fr_t b, uint64_t nin
 #define H2W_BN_LDS 0
 #endif
 constexpr int QST = H2W_QST;
-static_assert(QST >= 64, "the emitter stages a whole 64-cell mix layer");
+static_assert(QST == 32 || QST == 64, "the emitter stages a 64-cell mix layer whole (QST 64) or in two halves (QST 32)");
+constexpr int QHALVES = QST >= 64 ? 1 : 2;                  // staging passes per 4-lane layer: with QST 32 lanes 0-1 stage and flush first, then lanes 2-3
 constexpr int QUAD_BLOCK = H2W_QUAD_BLOCK;                   // threads per block of k_merkle_bn_quad: 4 wavefronts share one LDS copy of the constants
 struct __attribute__((aligned(16))) sq16_t { unsigned long long x, y; };
 __shared__ sq16_t s_quad_stage[(QUAD_BLOCK / 4) * QST * 2];
@@ -356,15 +357,20 @@ template <bool COLS> struct QuadSinkT {
         auto W64 = [&](int off, uint64_t v) { W(off, fr_from_u64(v)); };
         auto need = [&](int n) { if (so + n > QST) flush(outp, cc, base, so, l); };
         // x^5: 12 cells at region offset p (p < 0: this lane has no S-box here and keeps its s)
-        auto exp5 = [&](int p) {
+        auto exp5_all = [&]() {                          // S-box on every lane: 4 x 12 cells, lane l's at 12 l
             const fr_t X = fr_mont_mul(s, r2, ninv);
             const fr_t x2 = fr_mont_mul(s, X, ninv), X2 = fr_mont_mul(X, X, ninv);
             const fr_t x4 = fr_mont_mul(x2, X2, ninv), x5 = fr_mont_mul(x4, X, ninv);
-            const int q = p < 0 ? -64 : p;                            // q + i stays negative
-            W64(q, 0); W(q + 1, s); W(q + 2, s); W(q + 3, x2);
-            W64(q + 4, 0); W(q + 5, x2); W(q + 6, x2); W(q + 7, x4);
-            W64(q + 8, 0); W(q + 9, x4); W(q + 10, s); W(q + 11, x5);
-            if (p >= 0) s = x5;
+#pragma unroll
+            for (int h = 0; h < QHALVES; h++) {
+                need(48 / QHALVES);
+                const int q = QHALVES == 1 ? 12 * l : ((l >> 1) == h ? 12 * (l & 1) : -64);      // q + i stays negative for a lane without cells in this pass
+                W64(q, 0); W(q + 1, s); W(q + 2, s); W(q + 3, x2);
+                W64(q + 4, 0); W(q + 5, x2); W(q + 6, x2); W(q + 7, x4);
+                W64(q + 8, 0); W(q + 9, x4); W(q + 10, s); W(q + 11, x5);
+                so += 48 / QHALVES;
+            }
+            s = x5;
         };
         auto add_const = [&](int p, const fr_t &c) {                  // [c][s, c, 1, s+c]
             const int q = p < 0 ? -64 : p; const fr_t ns = fr_add(s, c);
@@ -375,14 +381,34 @@ template <bool COLS> struct QuadSinkT {
         auto ark = [&](int it) { const fr_t kc = bnk(0, BK_C + it + l); need(20); add_const(5 * l, kc); so += 20; };
         auto mix = [&](int which) {                      // which 0: M, 1: P
             if (!zc) { need(1); W64(l == 0 ? 0 : -64, 0); so += 1; zc = true; }
-            need(64);
-            fr_t acc = fr_zero(); const int p = 16 * l;
-            for (int j = 0; j < 4; j++) {
-                const fr_t sj = shfl4(s, j);
-                const fr_t nacc = fr_add(fr_mont_mul(sj, bnk(1, (which ? BK_P : BK_M) + 4 * j + l), ninv), acc);
-                W(p + 4 * j, acc); W(p + 4 * j + 1, bnk(0, (which ? BK_P : BK_M) + 4 * j + l)); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, nacc); acc = nacc;
+            if constexpr (QHALVES == 1) {
+                need(64);
+                fr_t acc = fr_zero(); const int p = 16 * l;
+                for (int j = 0; j < 4; j++) {
+                    const fr_t sj = shfl4(s, j);
+                    const fr_t nacc = fr_add(fr_mont_mul(sj, bnk(1, (which ? BK_P : BK_M) + 4 * j + l), ninv), acc);
+                    W(p + 4 * j, acc); W(p + 4 * j + 1, bnk(0, (which ? BK_P : BK_M) + 4 * j + l)); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, nacc); acc = nacc;
+                }
+                s = acc; so += 64;
+            } else {
+                // the canonical constants are requested before the first flush (loads and stores share vmcnt in order); the row's
+                // partial sums stay in registers across the two staging passes
+                fr_t kc[4], acc[5];
+#pragma unroll
+                for (int j = 0; j < 4; j++) kc[j] = bnk(0, (which ? BK_P : BK_M) + 4 * j + l);
+                acc[0] = fr_zero();
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j + 1] = fr_add(fr_mont_mul(shfl4(s, j), bnk(1, (which ? BK_P : BK_M) + 4 * j + l), ninv), acc[j]);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    need(32);
+                    const int p = (l >> 1) == h ? 16 * (l & 1) : -64;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const fr_t sj = shfl4(s, j); W(p + 4 * j, acc[j]); W(p + 4 * j + 1, kc[j]); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, acc[j + 1]); }
+                    so += 32;
+                }
+                s = acc[4];
             }
-            s = acc; so += 64;
         };
         auto consts32 = [&]() {                          // load_constant of M then P (full_rounds prologue)
             need(32);
@@ -398,7 +424,7 @@ template <bool COLS> struct QuadSinkT {
                     const int ix = (BN_WIDTH * 2 - 1) * r + l, lm = l > 0 ? l - 1 : 0, iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + lm;
                     const fr_t kc = bnk(0, BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r);
                     const fr_t ksx = bnk(0, BK_S + ix), ksxm = bnk(1, BK_S + ix), ksy = bnk(0, BK_S + iy), ksym = bnk(1, BK_S + iy);
-                    need(52);
+                    need(QST >= 64 ? 52 : 17);             // (QST 32: the round's three cell groups - 17, 20, 15 - are placed one by one)
                     // Five wavefront-level Montgomery products per partial round instead of seven: the lanes that have no S-box do
                     // their own work inside the S-box's instruction stream.
                     //   A: lane 0  X = s0 R          | lanes 1-3  S_j * s_j          (their terms of the sparse row; s_j is not touched by the S-box)
@@ -419,6 +445,7 @@ template <bool COLS> struct QuadSinkT {
                         if (l == 0) s = ns;
                     }
                     so += 17;
+                    if constexpr (QST < 64) need(20);
                     const fr_t s0 = shfl4(s, 0);
                     const fr_t E_ = fr_mont_mul(s0, l == 0 ? ksxm : ksym, ninv);
                     const fr_t pr = l == 0 ? E_ : A_;                                    // S[j] * s_j
@@ -427,6 +454,7 @@ template <bool COLS> struct QuadSinkT {
                     fr_t excl = shfl4_up(incl, 1); if (l == 0) excl = fr_zero();
                     { const int p = 5 * l; W(p, ksx); W(p + 1, excl); W(p + 2, ksx); W(p + 3, s); W(p + 4, incl); }
                     so += 20;
+                    if constexpr (QST < 64) need(15);
                     const fr_t ns0 = shfl4(incl, 3);
                     {
                         const int p = l > 0 ? 5 * lm : -64;
@@ -439,11 +467,11 @@ template <bool COLS> struct QuadSinkT {
             }
             consts32();
             for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
-                need(48); exp5(12 * l); so += 48;
+                exp5_all();
                 ark(half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
                 mix(0);
             }
-            need(48); exp5(12 * l); so += 48;
+            exp5_all();
             if (half == 0) { ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(1); } else mix(0);
         }
         flush(outp, cc, base, so, l);
