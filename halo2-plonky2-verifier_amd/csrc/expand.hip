@@ -149,7 +149,11 @@ template <int ABLATE, int TILE_RECS, int NSTEP, bool COLS = false> __global__ __
             ull cellidx = s_coff[i] + s;
             if constexpr (COLS) { if (s >= s_split[i]) cellidx += s_dd[i]; }
             u128s *dst = ABLATE == 0 ? (u128s *)(out + cellidx) : (u128s *)(out + s_coff[0] + j);
+#ifdef H2W_ABL_EXPAND_NOSTORE      // timing-only ablation: every cell is computed, (almost) none is written
+            if (vlo.lo == 0x123456789abcdefull && vhi.hi == 0x0fedcba987654321ull) { dst[0] = vlo; dst[1] = vhi; }
+#else
             dst[0] = vlo; dst[1] = vhi;
+#endif
         }
         __syncthreads();
         tile = dyn ? (uint64_t)s_next : tile + gridDim.x;
@@ -343,6 +347,141 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_r(ExpandArgs A) 
     }
 }
 
+// ---- the default kernel for plans without a literal pool (the batched hot path).  Same tiles, same bases, same stores as
+// expand_kernel_t, with fewer instructions per cell - overlapped batches are bound by instruction issue, not by HBM (DESIGN.md
+// "What bounds the whole job"):
+//   * cell -> record without a search: a wavefront's 64 consecutive cells form one aligned 64-cell chunk of the tile; the record lanes
+//     leave the record that holds each chunk's first cell in s_hint, so the wavefront reads a wave-uniform [first, last] record range
+//     (1-3 records at lookup_bits 21, where a template has <= 66 cells) and each lane counts the record starts at or below its cell;
+//   * one 16-byte LDS read per cell for the record's {first cell of the tile, slot base, advice offset};
+//   * constants and bases go through the same load / shift / mask sequence (a constant is "the whole 128 bits"), and the usual
+//     fields (shift < 64, no left shift) are cut out with 64-bit operations; other descriptors take the generic 128-bit path.
+struct __attribute__((aligned(16))) rec_info_t { uint32_t pre, sbase; ull coff; };
+constexpr int H_TILE_RECS = 32;
+static inline size_t hint_words(uint32_t max_cells) { return ((size_t)H_TILE_RECS * max_cells + 63) / 64 + 2; }      // chunk table of a tile
+template <bool COLS> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_h(ExpandArgs A) {
+    constexpr int TILE_RECS = H_TILE_RECS;
+    u128s *s_consts = reinterpret_cast<u128s *>(s_dyn_tables);
+    uint32_t *s_slots = reinterpret_cast<uint32_t *>(s_consts + A.nconsts * 2);
+    __shared__ tmpl_info_t s_info[T_MAX];
+    __shared__ u128s s_bases[TILE_RECS][B_COUNT];
+    __shared__ rec_info_t s_rec[TILE_RECS + 1];
+    uint32_t *s_hint = s_slots + A.nslots;                    // (TILE_RECS * max_cells + 63) / 64 + 2 words, dynamic like the tables
+    __shared__ uint32_t s_next;
+    __shared__ uint32_t s_split[COLS ? TILE_RECS : 1]; __shared__ ull s_dd[COLS ? TILE_RECS : 1];
+
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < A.nslots; i += EXPAND_THREADS) s_slots[i] = A.slots[i];
+    for (uint32_t i = tid; i < A.nconsts * 2; i += EXPAND_THREADS) s_consts[i] = ((const u128s *)A.consts)[i];
+    for (uint32_t i = tid; i < A.ntmpl; i += EXPAND_THREADS) s_info[i] = A.info[i];
+    __syncthreads();
+
+    const uint64_t proof = blockIdx.y;
+    const rec_t *recs = A.recs + proof * A.rec_stride;
+    fr_t *out = A.out + proof * A.cell_stride;
+    const uint64_t ntiles = (A.nrec + TILE_RECS - 1) / TILE_RECS;
+    const u128 two_rb = (u128)1 << A.rb;
+    const bool dyn = A.tile_ctr != nullptr;
+    uint64_t tile = blockIdx.x;
+    if (dyn) { if (tid == 0) s_next = atomicAdd(&A.tile_ctr[proof], 1u); __syncthreads(); tile = s_next; __syncthreads(); }
+    for (; tile < ntiles;) {
+        if (dyn && tid == 64) s_next = atomicAdd(&A.tile_ctr[proof], 1u);
+        const uint64_t r0 = tile * TILE_RECS;
+        const int nr = (int)((A.nrec - r0) < TILE_RECS ? (A.nrec - r0) : TILE_RECS);
+        if (tid < TILE_RECS) {
+            uint32_t n = 0, sbase = 0; ull coff = 0;
+            bool mine = tid < nr;
+            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block is kept by every rank
+                const uint64_t r = r0 + tid;
+                if (r >= A.q_rec0_first) {
+                    const uint64_t q = r < A.q_rec0_rest ? 0 : 1 + (r - A.q_rec0_rest) / A.q_nrec_rest;
+                    mine = (proof * A.nq + q) % A.shard_world == A.shard_rank;
+                }
+            }
+            if (mine) {
+                const uint64_t m = A.meta[r0 + tid];
+                const rec_t rc = recs[r0 + tid];
+                const uint32_t t = meta_tmpl(m);
+                const tmpl_info_t ti = s_info[t];
+                n = ti.ncells; sbase = ti.slot_base; coff = meta_off(m);
+                if constexpr (COLS) {
+                    ColCursor cc; cc.init(A.cm); cc.locate(coff);
+                    const ull room = cc.hi - coff, d0 = cc.delta;               // cells of this record before the next column starts
+                    ull dd = 0; uint32_t split = 0xffffffffu;
+                    if (room < 4096) { split = (uint32_t)room; cc.locate(cc.hi); dd = cc.delta - d0; }
+                    s_split[tid] = split; s_dd[tid] = dd; coff += d0;
+                }
+                u128 V, X0, X1;
+                if (ti.mode == M_WIDEV) V = ((u128)rc.b << 64) | rc.a; else V = (u128)rc.a * rc.b + rc.c;
+                if (ti.mode == M_LOADW) { X0 = rc.a; X1 = rc.b; }
+                else {      // hint of GoldilocksChip::reduce (base.rs:349-352), divider-free: see expand_kernel_t
+                    const uint64_t r = gl_reduce128(V);
+                    const u128 Dv = V - r;
+                    const uint64_t dl = (uint64_t)Dv;
+                    const uint64_t qlo = dl + (dl << 32);
+                    const uint64_t qhi = ((u128)qlo * GL_P != Dv) ? 1 : 0;
+                    X0 = gl_reduce128(((u128)qhi << 64) | qlo); X1 = r;
+                }
+                u128 b[B_COUNT];
+                b[B_A] = rc.a; b[B_B] = rc.b; b[B_C] = rc.c; b[B_D] = rc.d; b[B_V] = V;
+                b[B_X0] = X0; b[B_X0P] = X0 + two_rb - GL_P; b[B_X0PP] = X0 + two_rb;
+                b[B_X1] = X1; b[B_X1P] = X1 + two_rb - GL_P; b[B_X1PP] = X1 + two_rb; b[B_W] = X0 * (u128)GL_P + X1;
+#pragma unroll
+                for (int k = 0; k < B_COUNT; k++) { s_bases[tid][k].lo = (ull)b[k]; s_bases[tid][k].hi = (ull)(b[k] >> 64); }
+            }
+            // inclusive scan over the 32 record lanes (wave-level shuffles; lanes 0..31 of wave 0)
+            uint32_t x = n;
+#pragma unroll
+            for (int d = 1; d < TILE_RECS; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (tid >= d) x += y; }
+            const uint32_t first = x - n;                                  // this record's first cell in the tile
+            rec_info_t ri; ri.pre = first; ri.sbase = sbase; ri.coff = coff; s_rec[tid] = ri;
+            if (n) for (uint32_t c = (first + 63) >> 6; (c << 6) < x; c++) s_hint[c] = (uint32_t)tid;      // chunks whose first cell is mine (<= 2)
+            if (tid == TILE_RECS - 1) { rec_info_t e; e.pre = x; e.sbase = 0; e.coff = 0; s_rec[TILE_RECS] = e; s_hint[(x + 63) >> 6] = (uint32_t)(nr - 1); }
+        }
+        __syncthreads();
+        const uint32_t total = s_rec[TILE_RECS].pre;
+        for (uint32_t cb = (uint32_t)(tid & ~63); cb < total; cb += EXPAND_THREADS) {      // cb: first cell of this wavefront's chunk
+            const uint32_t j = cb + (uint32_t)(tid & 63);
+            const int i0 = __builtin_amdgcn_readfirstlane((int)s_hint[cb >> 6]);
+            int ihi = __builtin_amdgcn_readfirstlane((int)s_hint[(cb >> 6) + 1]);
+            if (cb + 64 >= total) ihi = nr - 1;
+            int i = i0;
+            for (int k = i0 + 1; k <= ihi; k++) i += (s_rec[k].pre <= j) ? 1 : 0;
+            if (j < total) {
+                const rec_info_t ri = s_rec[i];
+                const uint32_t sidx = j - ri.pre;
+                const uint32_t d = s_slots[ri.sbase + sidx];
+                const bool is_const = (d >> 31) != 0;
+                const u128s *src = is_const ? &s_consts[(d & 0xffffu) * 2] : &s_bases[i][d & 15u];
+                const u128s bs = src[0];
+                u128s vlo, vhi; vhi.lo = 0; vhi.hi = 0;
+                if (is_const) vhi = src[1];
+                if (!is_const && (d & ((127u << 19) | (64u << 4)))) {          // left-shifted or far field: generic 128-bit path (rare)
+                    u128 v = ((u128)bs.hi << 64) | bs.lo;
+                    const uint32_t sh = (d >> 4) & 127u, w = (d >> 11) & 255u, ls = (d >> 19) & 127u;
+                    v >>= sh;
+                    if (w < 128) v &= (((u128)1 << w) - 1);
+                    v <<= ls;
+                    vlo.lo = (ull)v; vlo.hi = (ull)(v >> 64);
+                } else {
+                    const uint32_t sh = is_const ? 0u : (d >> 4) & 63u, w = is_const ? 128u : (d >> 11) & 255u;
+                    ull nlo = (bs.lo >> sh) | ((bs.hi << 1) << (63u - sh)), nhi = bs.hi >> sh;
+                    const ull m = ((ull)1 << (w & 63u)) - 1;
+                    vlo.lo = w < 64 ? (nlo & m) : nlo;
+                    vlo.hi = w < 64 ? 0 : (w < 128 ? (nhi & m) : nhi);
+                }
+                ull cellidx = ri.coff + sidx;
+                if constexpr (COLS) { if (sidx >= s_split[i]) cellidx += s_dd[i]; }
+                u128s *dst = (u128s *)(out + cellidx);
+                dst[0] = vlo; dst[1] = vhi;
+            }
+        }
+        __syncthreads();
+        tile = dyn ? (uint64_t)s_next : tile + gridDim.x;
+        if (dyn) __syncthreads();          // s_next is rewritten at the top of the next tile
+    }
+}
+
 static int expand_variant() { static int v = -1; if (v < 0) { const char *e = getenv("H2W_EXPAND_VARIANT"); v = e ? atoi(e) : 0; } return v; }
 
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
@@ -353,7 +492,11 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
     uint64_t gx = (uint64_t)grid_x; if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)nproofs);
     const size_t dyn = ((size_t)A.nconsts * 32 + (size_t)A.nslots * 4 + 15) & ~(size_t)15;      // expand_kernel_t's tables
-    if (A.cm.starts) hipLaunchKernelGGL((expand_kernel_t<0, 32, 5, true>), grid, dim3(EXPAND_THREADS), dyn, stream, A);      // the A/B variants write flat only
+    const bool hinted = A.pool == nullptr && A.max_cells > 0 && A.max_cells <= 1024 && expand_variant() == 3;     // (literal runs can be longer than a chunk table: expand_kernel_t keeps those)
+    const size_t dyn_h = ((size_t)A.nconsts * 32 + ((size_t)A.nslots + hint_words(A.max_cells)) * 4 + 15) & ~(size_t)15;
+    if (hinted && A.cm.starts) hipLaunchKernelGGL((expand_kernel_h<true>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
+    else if (hinted) hipLaunchKernelGGL((expand_kernel_h<false>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
+    else if (A.cm.starts) hipLaunchKernelGGL((expand_kernel_t<0, 32, 5, true>), grid, dim3(EXPAND_THREADS), dyn, stream, A);      // the A/B variants write flat only
     else if (expand_variant() == 2) hipLaunchKernelGGL(expand_kernel_r, grid, dim3(EXPAND_THREADS), 0, stream, A);
     else if (expand_variant() == 1) hipLaunchKernelGGL(expand_kernel_w, grid, dim3(EXPAND_THREADS), 0, stream, A);
     else if (expand_variant() == 11) hipLaunchKernelGGL((expand_kernel_t<1, 32, 5>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
