@@ -163,7 +163,9 @@ def main():
         # valid FRI instances (SURVEY 8d variant (A)): random committed polynomials, proved on the ingest rank's GPU in lockstep batches;
         # the proofs never visit the host.  Every distinct proof is used (no repetition inside a step).
         all_proofs = torch.zeros(total_proofs * words, dtype=torch.int64, device=dev)
+        gen_seconds = None
         if rank == 0:
+            t_gen = time.perf_counter()
             pr = api.Prover(shape, consts, local_rank)
             assert pr.proof_words == words
             gen = torch.Generator(device=dev); gen.manual_seed(0xF1B00000)
@@ -173,6 +175,7 @@ def main():
                 coefs = torch.randint(0, 1 << 62, (nb * pr.num_polys << d,), dtype=torch.int64, device=dev, generator=gen)   # < 2^62 < p: canonical
                 pr.prove_batch(coefs.data_ptr(), [1, 1, 2] * nb, all_proofs[first * words:].data_ptr(), nb, torch.cuda.current_stream(dev).cuda_stream)
             torch.cuda.synchronize(dev)
+            gen_seconds = time.perf_counter() - t_gen
             pr.close(); del coefs
             torch.cuda.empty_cache()
         D.broadcast_proofs(all_proofs, src=0)       # the only collective (RCCL over xGMI): ingest rank -> all ranks
@@ -281,6 +284,7 @@ def main():
                        "proofs": "valid FRI instances of random polynomials, generated on the GPU by the ingest rank (h2w_prove_fri_batch)" if args.proofs == "valid" and args.backend != "gloo" else "uniform random words of the proof's shape",
                        "parallelism": f"proof-sharded x{world}, no data-path collective"},
             "proofs_per_s": total_proofs * args.steps / elapsed,
+            "input_generation": ({"proofs": total_proofs, "seconds": round(gen_seconds, 3), "proofs_per_s": round(total_proofs / gen_seconds, 1), "where": "GPU of rank 0, outside the timed region"} if args.proofs == "valid" and args.backend != "gloo" and gen_seconds else None),
             "advice_GBps": value * 32 / 1e9,
             "kernel_ms_isolated": {"prologue": isol[0], "strands": isol[1], "bn254_units": isol[2], "expand": isol[3], "batch": isol[4]},
             "kernel_ms_timed_region": {"prologue": overl[0], "strands": overl[1], "bn254_units": overl[2], "expand": overl[3], "batch": overl[4]},
