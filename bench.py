@@ -81,14 +81,15 @@ def cpu_baseline_all_cores(shape_args, hash_mode, lookup_bits, cells_per_proof, 
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 32 << 30
-    workers = max(1, min(ncores, int(0.5 * avail // (cells_per_proof * 40))))
+    share = int(os.environ.get("H2W_CPU_SHARE", "16"))      # the GPU box gives one GPU's job a 16-core CPU share, whatever its affinity mask shows
+    workers = max(1, min(ncores, share, int(0.5 * avail // (cells_per_proof * 40))))
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps([list(shape_args), hash_mode, lookup_bits, budget_s])]
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(workers)]
     res = [json.loads(p.communicate(timeout=budget_s * 6 + 120)[0].strip().splitlines()[-1]) for p in procs]
     wall = time.perf_counter() - t0
     cells = sum(r["cells"] for r in res); n = sum(r["proofs"] for r in res); span = max(r["seconds"] for r in res)
-    return {"value": cells / span, "unit": "cells/s", "cores": workers, "host_cores": ncores, "kind": "port",
+    return {"value": cells / span, "unit": "cells/s", "cores": workers, "host_cores_visible": ncores, "cpu_share": share, "kind": "port",
             "sample": f"{n} proof(s) of the same shape over {workers} single-threaded oracle processes ({span:.1f} s of work each, {wall:.1f} s wall incl. start-up)",
             "proofs_per_s": n / span}
 
