@@ -158,3 +158,58 @@ def test_full_width_mds_constants(h2w, h2w_api, oracle, consts):
     coefs, pis, d_proof, _ = gpu_prove(h2w, h2w_api, oracle, kh, sh, osh, 78)
     want = np.frombuffer(oracle.prove_fri_coef(osh, ko, coefs, pis), dtype=np.uint64)
     assert (d_proof.cpu().numpy().view(np.uint64) == want).all()
+
+
+def _witness_of(h2w_api, plan, d_proofs, n):
+    import torch
+    advice = torch.zeros(n * plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert plan.status(ws.data_ptr(), n) == [0] * n
+    return advice
+
+
+def test_config4_pipeline_on_the_device(h2w, h2w_api, oracle, published):
+    """BASELINE.json configs[3] at 1/16 scale on one GPU: 16 independent 2^16-row proofs (28 queries, rate_bits 2) generated in one
+    lockstep batch, witnessed in one batch, every gate and lookup checked on the device; two of the 16 advice streams are compared
+    with the oracle's, byte for byte (the proofs never leave the device except for that comparison)."""
+    import numpy as np
+    import torch
+    ko, kh = published
+    n = 16
+    sh = h2w.fibonacci_shape(16, 28, rate_bits=2, hash_mode=1); osh = oracle.fibonacci_shape(16, 28, rate_bits=2, hash_mode=1)
+    pr = h2w_api.Prover(sh, kh)
+    g = torch.Generator(device="cuda"); g.manual_seed(404)
+    coefs = torch.randint(0, 1 << 62, (n * pr.num_polys << 16,), dtype=torch.int64, device="cuda", generator=g)
+    proofs = torch.zeros(n * pr.proof_words, dtype=torch.int64, device="cuda")
+    pr.prove_batch(coefs.data_ptr(), [7, 8, 9] * n, proofs.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize(); pr.close()
+    plan = h2w_api.Plan(sh, kh)
+    advice = _witness_of(h2w_api, plan, proofs, n)
+    assert plan.check_constraints(advice.data_ptr(), n) == (0, 0)
+    host = proofs.cpu().numpy().view(np.uint64).reshape(n, plan.proof_words)
+    assert len({host[i].tobytes() for i in range(n)}) == n                      # independent instances
+    for i in (0, n - 1):
+        ctx = oracle.Ctx(21)
+        assert oracle.verify_stark(ctx, osh, ko, (C.c_uint64 * plan.proof_words).from_buffer_copy(host[i].tobytes())) == 0
+        assert advice[i * plan.num_cells * 32:(i + 1) * plan.num_cells * 32].cpu().numpy().tobytes() == ctx.advice_bytes()
+        ctx.close()
+    plan.close()
+
+
+def test_config5_valid_proof(h2w, h2w_api, oracle, published):
+    """BASELINE.json configs[4]: 2^20 rows, 84 queries, PoseidonBN254 caps of height 4: a GPU-generated valid instance, its
+    59.7 M + load cells checked gate by gate on the device and compared with the oracle's stream."""
+    import torch
+    ko, kh = published
+    sh = h2w.fibonacci_shape(20, 84, rate_bits=1, hash_mode=1); osh = oracle.fibonacci_shape(20, 84, rate_bits=1, hash_mode=1)
+    _, _, d_proof, _ = gpu_prove(h2w, h2w_api, oracle, kh, sh, osh, 0xF1B00005)
+    plan = h2w_api.Plan(sh, kh)
+    advice = _witness_of(h2w_api, plan, d_proof, 1)
+    assert plan.check_constraints(advice.data_ptr(), 1) == (0, 0)
+    ctx = oracle.Ctx(21); ctx.reserve(plan.num_cells)
+    assert oracle.verify_stark(ctx, osh, ko, (C.c_uint64 * plan.proof_words).from_buffer_copy(d_proof.cpu().numpy().tobytes())) == 0
+    assert ctx.num_cells() == plan.num_cells == 59708779 + 328424                    # SURVEY 8d: verify_proof cells + witness-load cells
+    assert advice.cpu().numpy().tobytes() == ctx.advice_bytes()
+    ctx.close(); plan.close()
