@@ -210,6 +210,6 @@ def test_config5_valid_proof(h2w, h2w_api, oracle, published):
     assert plan.check_constraints(advice.data_ptr(), 1) == (0, 0)
     ctx = oracle.Ctx(21); ctx.reserve(plan.num_cells)
     assert oracle.verify_stark(ctx, osh, ko, (C.c_uint64 * plan.proof_words).from_buffer_copy(d_proof.cpu().numpy().tobytes())) == 0
-    assert ctx.num_cells() == plan.num_cells == 59708779 + 328424                    # verify_proof cells + witness-load cells
+    assert ctx.num_cells() == plan.num_cells == 59708779 + 328424 + 1                # verify_proof cells + witness-load cells + the flow's load_zero (stark/mod.rs:483-508)
     assert advice.cpu().numpy().tobytes() == ctx.advice_bytes()
     ctx.close(); plan.close()
