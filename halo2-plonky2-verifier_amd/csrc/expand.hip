@@ -445,8 +445,11 @@ template <bool COLS> __global__ __launch_bounds__(EXPAND_THREADS) void expand_ke
             const int i0 = __builtin_amdgcn_readfirstlane((int)s_hint[cb >> 6]);
             int ihi = __builtin_amdgcn_readfirstlane((int)s_hint[(cb >> 6) + 1]);
             if (cb + 64 >= total) ihi = nr - 1;
-            int i = i0;
-            for (int k = i0 + 1; k <= ihi; k++) i += (s_rec[k].pre <= j) ? 1 : 0;
+            // records after ihi start at or after the next chunk (or at `total`), so comparing three more starts unconditionally is
+            // exact whenever the chunk holds at most four records (templates of 16+ cells); runs of tiny templates take the loop
+            int i = i0 + (s_rec[i0 + 1].pre <= j ? 1 : 0) + (s_rec[i0 + 2 <= TILE_RECS ? i0 + 2 : TILE_RECS].pre <= j ? 1 : 0)
+                       + (s_rec[i0 + 3 <= TILE_RECS ? i0 + 3 : TILE_RECS].pre <= j ? 1 : 0);
+            if (ihi > i0 + 3) for (int k = i0 + 4; k <= ihi; k++) i += (s_rec[k].pre <= j) ? 1 : 0;
             if (j < total) {
                 const rec_info_t ri = s_rec[i];
                 const uint32_t sidx = j - ri.pre;
