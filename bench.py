@@ -294,7 +294,7 @@ def main():
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS,
                          "note": f"expand_kernel launched alone ({len(iso)} calibration launches after the timed region, library HIP events on the launch stream): 32 B x {exp_cells} cells per launch ({plan.num_record_cells} of {plan.num_cells} cells/proof come from block records; the others are PoseidonBN254 permutation units / direct cells); record+meta reads {B * rec_bytes / 1e6:.1f} MB extra. whole_job_frac = value x 32 B / peak (all kernels, overlapped batches)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU legs run at N = 1 only (rank 0's host)
             out["cpu_baseline"] = cpu_baseline((d, q, rb), hash_mode, args.lookup_bits)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores((d, q, rb), hash_mode, args.lookup_bits, plan.num_cells)
