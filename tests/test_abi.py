@@ -85,3 +85,27 @@ def test_no_cpu_fallback(h2w_api, h2w):
     with pytest.raises(h2w_api.H2WError, match="no HIP device"):
         ctx.advice_bytes()
     ctx.close()
+
+
+def test_prover_has_no_cpu_path_and_rejects_bad_shapes(h2w_api, h2w):
+    """h2w_prover_new: without a HIP device it fails loudly (proof generation exists on the GPU only); unsupported shapes are
+    refused with an error string instead of a crash."""
+    kh = h2w.published_consts()
+    if h2w.lib().h2w_device_count() == 0:
+        with pytest.raises(h2w_api.H2WError, match="no HIP device"):
+            h2w_api.Prover(h2w.fibonacci_shape(6, 2), kh)
+        return
+    bad = h2w.fibonacci_shape(6, 2); bad.arity_bits = 7
+    with pytest.raises(h2w_api.H2WError, match="unsupported shape"):
+        h2w_api.Prover(bad, kh)
+    bad = h2w.fibonacci_shape(6, 2); bad.n_cols = 40
+    with pytest.raises(h2w_api.H2WError, match="unsupported shape"):
+        h2w_api.Prover(bad, kh)
+
+
+def test_published_tables_are_a_plain_data_call(h2w):
+    """h2w_poseidon_published needs no device; a null pointer is an error, not a crash."""
+    assert h2w.lib().h2w_poseidon_published(None) != 0
+    assert "null" in h2w.last_error()
+    k = h2w.published_consts()
+    assert k.mds_circ[0] == 17 and k.mds_diag[0] == 8 and k.all_round_constants[0] == 0xb585f766f2144405
