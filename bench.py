@@ -259,6 +259,18 @@ def main():
     iso = iso[1:] if len(iso) > 1 else iso
     isol = [sum(t[k] for t in iso) / len(iso) for k in range(5)] if iso else overl
     exp_ms = isol[3]
+    # (c) the same kernel with its launches back to back: every stream re-expands the records of its last batch
+    #     (h2w_fri_expand_records: expansion kernel only), three rounds over all streams; aggregate bytes / wall time.
+    b2b_gbs = None
+    if args.calib > 0 and not args.cu_split:
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        rounds = 3
+        for _ in range(rounds):
+            for i in range(S):
+                plan.expand_records(B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
+        torch.cuda.synchronize()
+        b2b_gbs = rounds * S * B * plan.num_record_cells * 32 / (time.perf_counter() - tb) / 1e9
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), when they cover this workload
     traffic = None
@@ -292,7 +304,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": exp_cells * 32, "kernel": "expand_kernel",
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS,
-                         "note": f"expand_kernel launched alone ({len(iso)} calibration launches after the timed region, library HIP events on the launch stream): 32 B x {exp_cells} cells per launch ({plan.num_record_cells} of {plan.num_cells} cells/proof come from block records; the others are PoseidonBN254 permutation units / direct cells); record+meta reads {B * rec_bytes / 1e6:.1f} MB extra. whole_job_frac = value x 32 B / peak (all kernels, overlapped batches)"},
+                         "achieved_back_to_back": b2b_gbs, "frac_back_to_back": (b2b_gbs / HBM_PEAK_GBS if b2b_gbs else None),
+                         "note": f"expand_kernel launched alone ({len(iso)} calibration launches after the timed region, library HIP events on the launch stream): 32 B x {exp_cells} cells per launch ({plan.num_record_cells} of {plan.num_cells} cells/proof come from block records; the others are PoseidonBN254 permutation units / direct cells); record+meta reads {B * rec_bytes / 1e6:.1f} MB extra. whole_job_frac = value x 32 B / peak (all kernels, overlapped batches); achieved_back_to_back = the same kernel alone with its launches back to back on the bench's streams (h2w_fri_expand_records, 3 rounds), aggregate bytes / wall time"},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU legs run at N = 1 only (rank 0's host)
             out["cpu_baseline"] = cpu_baseline((d, q, rb), hash_mode, args.lookup_bits)

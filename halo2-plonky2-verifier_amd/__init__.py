@@ -134,6 +134,7 @@ SYMBOLS = {
     "h2w_plan_num_records": (C.c_uint64, [_vp]),
     "h2w_plan_workspace_bytes": (C.c_uint64, [_vp, C.c_uint64]),
     "h2w_fri_witness_batch": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "h2w_fri_expand_records": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp]),
     "h2w_fri_witness_batch2": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "h2w_plan_num_gates": (C.c_uint64, [_vp]),
     "h2w_plan_num_lookups": (C.c_uint64, [_vp]),

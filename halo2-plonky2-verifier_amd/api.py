@@ -233,6 +233,10 @@ class Plan:
         else:
             _ck(self.L.h2w_fri_witness_batch2(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, emit_stream), "h2w_fri_witness_batch2")
 
+    def expand_records(self, n, advice_ptr, workspace_ptr, stream=0):
+        """The expansion kernel alone over the records a previous run() left in the workspace (measurement)."""
+        _ck(self.L.h2w_fri_expand_records(self.p, n, advice_ptr, workspace_ptr, stream), "h2w_fri_expand_records")
+
     def status(self, workspace_ptr, n, stream=0):
         st = (C.c_uint32 * n)()
         _ck(self.L.h2w_plan_status(self.p, workspace_ptr, n, st, stream), "h2w_plan_status")

@@ -675,6 +675,29 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     H2W_HIP(hipGetLastError());
     return 0;
 }
+// Re-expands the block records a previous h2w_fri_witness_batch* call left in `workspace_dev` (same n_proofs) into advice_dev: the
+// expansion kernel alone, for measuring its streaming rate (bench.py roofline).  Cells written by the value kernels are not touched.
+int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
+    if (!p || p->device < 0) { set_error("h2w_fri_expand_records: no HIP device"); return -1; }
+    if (!advice_dev || !workspace_dev) { set_error("h2w_fri_expand_records: null buffer"); return -1; }
+    if (n_proofs == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
+    char *ws = (char *)workspace_dev;
+    ExpandArgs E;
+    E.meta = p->d_meta; E.recs = (rec_t *)(ws + o_recs); E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = (fr_t *)advice_dev; E.cell_stride = p->ncells; E.pool = nullptr;
+    E.cm = ColMap{nullptr, 0, 0};
+    E.shard_rank = 0; E.shard_world = 1; E.nq = (uint32_t)p->shape.num_queries;
+    E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
+    if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
+    p->dt.fill(E); E.rb = p->tt.rb;
+    E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
+    H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), stream));
+    int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
+    launch_expand(E, n_proofs, gx, stream);
+    H2W_HIP(hipGetLastError());
+    return 0;
+}
 // ---- keygen-side metadata of the cell stream: static per shape, computed by a second host replay
 int h2w_plan_metadata(h2w_plan *pl) {
     if (!pl) { set_error("h2w_plan_metadata: null plan"); return -1; }

@@ -180,6 +180,9 @@ int h2w_fri_witness_batch(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_pro
  * waits for it).  Lets a caller give the latency-bound value strands and the streaming kernel differently CU-masked streams. */
 int h2w_fri_witness_batch2(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs,
                            void *advice_dev, void *workspace_dev, void *stream, void *emit_stream);
+/* The expansion kernel alone: re-expands the block records a previous h2w_fri_witness_batch* call (same n_proofs) left in
+ * workspace_dev into advice_dev (flat layout).  Cells the value kernels write directly are not touched.  For measurement. */
+int h2w_fri_expand_records(h2w_plan *, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream);
 /* ---- keygen-side bookkeeping of an eager context created with witness_gen_only == 0 (halo2-base Context when
  * witness_gen_only is false; semantics [R]): gate cells (selector on), range-lookup registrations (in order),
  * copy constraints (advice_equalities: pairs of cell offsets) and constant equalities (cell, constant). */

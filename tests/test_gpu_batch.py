@@ -288,3 +288,28 @@ def test_device_status_where_reference_panics(h2w, h2w_api, oracle, consts):
     with pytest.raises(h2w_api.H2WError):
         h2w_api.Plan(bad, kh)
     plan.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_expand_records_alone_rewrites_the_same_cells(h2w, h2w_api, oracle, consts, mode):
+    """h2w_fri_expand_records (the expansion kernel alone, used by bench.py's roofline leg): wiping every cell and re-expanding the
+    records left in the workspace restores exactly the cells that come from block records; the cells the value kernels write
+    directly stay wiped, and their number is num_cells - num_record_cells."""
+    import numpy as np
+    import torch
+    ko, kh = consts
+    sh = h2w.fibonacci_shape(8, 3, rate_bits=1, hash_mode=mode); osh = oracle.fibonacci_shape(8, 3, rate_bits=1, hash_mode=mode)
+    plan = h2w_api.Plan(sh, kh)
+    proofs = [oracle.synth_proof(osh, s) for s in (5, 6)]
+    host = torch.cat([torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64) for p in proofs]).cuda()
+    advice = torch.zeros(2 * plan.num_cells * 32, dtype=torch.uint8, device="cuda"); ws = torch.zeros(plan.workspace_bytes(2), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    plan.run(host.data_ptr(), 2, advice.data_ptr(), ws.data_ptr(), st); torch.cuda.synchronize()
+    full = advice.cpu().numpy().reshape(2 * plan.num_cells, 32).copy()
+    advice.fill_(0xEE)
+    plan.expand_records(2, advice.data_ptr(), ws.data_ptr(), st); torch.cuda.synchronize()
+    again = advice.cpu().numpy().reshape(2 * plan.num_cells, 32)
+    wiped = (again == 0xEE).all(axis=1)
+    assert int(wiped.sum()) == 2 * (plan.num_cells - plan.num_record_cells)
+    assert (again[~wiped] == full[~wiped]).all()
+    plan.close()
