@@ -357,10 +357,9 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_r(ExpandArgs A) 
 //   * constants and bases go through the same load / shift / mask sequence (a constant is "the whole 128 bits"), and the usual
 //     fields (shift < 64, no left shift) are cut out with 64-bit operations; other descriptors take the generic 128-bit path.
 struct __attribute__((aligned(16))) rec_info_t { uint32_t pre, sbase; ull coff; };
-constexpr int H_TILE_RECS = 32;
-static inline size_t hint_words(uint32_t max_cells) { return ((size_t)H_TILE_RECS * max_cells + 63) / 64 + 2; }      // chunk table of a tile
-template <bool COLS> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_h(ExpandArgs A) {
-    constexpr int TILE_RECS = H_TILE_RECS;
+static inline size_t hint_words(uint32_t max_cells, int tile_recs) { return ((size_t)tile_recs * max_cells + 63) / 64 + 2; }      // chunk table of a tile
+template <bool COLS, int TILE_RECS> __global__ __launch_bounds__(EXPAND_THREADS) void expand_kernel_h(ExpandArgs A) {
+    static_assert(TILE_RECS == 32 || TILE_RECS == 64, "the record lanes are one wavefront's");
     u128s *s_consts = reinterpret_cast<u128s *>(s_dyn_tables);
     uint32_t *s_slots = reinterpret_cast<uint32_t *>(s_consts + A.nconsts * 2);
     __shared__ tmpl_info_t s_info[T_MAX];
@@ -489,16 +488,17 @@ static int expand_variant() { static int v = -1; if (v < 0) { const char *e = ge
 
 void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
     if (A.nrec == 0 || nproofs == 0) return;
-    const int TILE_RECS = expand_variant() == 16 ? 16 : expand_variant() == 64 ? 64 : (expand_variant() == 1 || expand_variant() == 2) ? 64 : 32;
+    const int TILE_RECS = expand_variant() == 16 ? 16 : (expand_variant() == 64 || (expand_variant() == 364 && !A.cm.starts)) ? 64 : (expand_variant() == 1 || expand_variant() == 2) ? 64 : 32;
     uint64_t ntiles = (A.nrec + TILE_RECS - 1) / TILE_RECS;
     { static int ov = -2; if (ov == -2) { const char *e = getenv("H2W_EXPAND_BLOCKS"); ov = e ? atoi(e) : -1; } if (ov > 0) grid_x = (int)((uint64_t)ov / nproofs) + 1; }
     uint64_t gx = (uint64_t)grid_x; if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)nproofs);
     const size_t dyn = ((size_t)A.nconsts * 32 + (size_t)A.nslots * 4 + 15) & ~(size_t)15;      // expand_kernel_t's tables
-    const bool hinted = A.pool == nullptr && A.max_cells > 0 && A.max_cells <= 1024 && expand_variant() == 3;     // (literal runs can be longer than a chunk table: expand_kernel_t keeps those)
-    const size_t dyn_h = ((size_t)A.nconsts * 32 + ((size_t)A.nslots + hint_words(A.max_cells)) * 4 + 15) & ~(size_t)15;
-    if (hinted && A.cm.starts) hipLaunchKernelGGL((expand_kernel_h<true>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
-    else if (hinted) hipLaunchKernelGGL((expand_kernel_h<false>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
+    const bool hinted = A.pool == nullptr && A.max_cells > 0 && A.max_cells <= 512 && (expand_variant() == 3 || expand_variant() == 364);     // (literal runs can be longer than a chunk table: expand_kernel_t keeps those)
+    const size_t dyn_h = ((size_t)A.nconsts * 32 + ((size_t)A.nslots + hint_words(A.max_cells, TILE_RECS)) * 4 + 15) & ~(size_t)15;
+    if (hinted && A.cm.starts) hipLaunchKernelGGL((expand_kernel_h<true, 32>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
+    else if (hinted && TILE_RECS == 64) hipLaunchKernelGGL((expand_kernel_h<false, 64>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
+    else if (hinted) hipLaunchKernelGGL((expand_kernel_h<false, 32>), grid, dim3(EXPAND_THREADS), dyn_h, stream, A);
     else if (A.cm.starts) hipLaunchKernelGGL((expand_kernel_t<0, 32, 5, true>), grid, dim3(EXPAND_THREADS), dyn, stream, A);      // the A/B variants write flat only
     else if (expand_variant() == 2) hipLaunchKernelGGL(expand_kernel_r, grid, dim3(EXPAND_THREADS), 0, stream, A);
     else if (expand_variant() == 1) hipLaunchKernelGGL(expand_kernel_w, grid, dim3(EXPAND_THREADS), 0, stream, A);
