@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = auto)")
     ap.add_argument("--lookup-bits", type=int, default=21)
     ap.add_argument("--streams", type=int, default=0, help="batches in flight, each on its own HIP stream with its own advice/workspace buffers (0 = auto)")
+    ap.add_argument("--advice-cap-gb", type=float, default=200.0, help="upper bound on the advice buffers of all batches in flight (the stream count is reduced to fit)")
     ap.add_argument("--calib", type=int, default=5, help="isolated single-stream launches after the timed region for the roofline numbers")
     ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -198,7 +199,7 @@ def main():
     # S batches in flight: step k runs on stream k % S into its own advice / workspace buffers, so the latency-bound
     # value strands of one batch (serial Fiat-Shamir sponge, Merkle chains) overlap the HBM-bound kernels of another.
     S = args.streams if args.streams > 0 else (6 if hash_mode == 1 else 3)
-    while S > 1 and S * B * cell_bytes > 200e9:   # stay well inside the 288 GB of HBM
+    while S > 1 and S * B * cell_bytes > args.advice_cap_gb * 1e9:   # stay inside the 288 GB of HBM
         S -= 1
     advices = [torch.empty(B * cell_bytes, dtype=torch.uint8, device=dev) for _ in range(S)]
     wss = [torch.empty(plan.workspace_bytes(B), dtype=torch.uint8, device=dev) for _ in range(S)]
