@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # several batches are in flight on separate HIP streams; ROCm maps streams onto 4 hardware queues by default, which would
 # serialise them pairwise.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 CONFIGS = {
     # name: (degree_bits, num_queries, rate_bits, description)
@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--calib", type=int, default=5, help="isolated single-stream launches after the timed region for the roofline numbers")
     ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fork", action="store_true", help="experiment: PoseidonBN254 chain kernels on the caller's stream (H2W_OPT_FORK_CHAINS = 0)")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment: CU-masked streams, value strands on the first N CUs, expansion on the rest")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -151,6 +152,8 @@ def main():
     import numpy as np
     consts = h2w.published_consts()
     plan = api.Plan(shape, consts, local_rank)
+    if args.no_fork:
+        plan.configure(1, 0)
 
     cell_bytes = plan.num_cells * 32
     if args.batch > 0:

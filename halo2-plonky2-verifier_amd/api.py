@@ -233,6 +233,9 @@ class Plan:
         else:
             _ck(self.L.h2w_fri_witness_batch2(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, emit_stream), "h2w_fri_witness_batch2")
 
+    def configure(self, option, value):
+        _ck(self.L.h2w_plan_configure(self.p, option, value), "h2w_plan_configure")
+
     def expand_records(self, n, advice_ptr, workspace_ptr, stream=0):
         """The expansion kernel alone over the records a previous run() left in the workspace (measurement)."""
         _ck(self.L.h2w_fri_expand_records(self.p, n, advice_ptr, workspace_ptr, stream), "h2w_fri_expand_records")

@@ -23,8 +23,6 @@ namespace h2w {
 typedef ValBackend<DevSink> DevB;
 typedef ChallengeBlock<DevB> DevCB;   // (the wire types of every backend coincide: one ChallengeBlock layout)
 
-static const void *g_const_owner = nullptr;
-
 struct PlanSink {
     static constexpr bool kCoop = false;
     void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
@@ -34,8 +32,6 @@ struct PlanSink {
     std::vector<LoadItem> *items = nullptr;
     void note_load(uint64_t w, int kind) { LoadItem it; it.word = (uint32_t)w; it.kind = (uint32_t)kind; it.rec = nrec; it.cell = cell_off; items->push_back(it); }
     bool coop_load_proof(const ValCfg &) { return false; }
-    void bn_native(fr_t *, const h2w_poseidon_consts_t *, const FrParams &) {}
-    bool unit_writer() const { return false; }
     bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     int coop_lanes() { return 1; }
     int coop_lane() { return 0; }
@@ -79,7 +75,7 @@ struct BatchArgs {
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
     StrandTable st; FrParams P;
     int nproofs, role_base, dbg_skip_perm;
-    fr_t *units; uint64_t unit_stride; const h2w_poseidon_consts_t *consts_mont; const uint64_t *unit_cell; uint64_t bn_perm_cells;
+    const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
     ColMap cm;      // column-major emission (starts == nullptr: flat advice)
     int shard_rank, shard_world;      // (proof, query) units are dealt round-robin to shard_world ranks (1: everything)
@@ -90,15 +86,14 @@ __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
     c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = &A.st; c.split = true;
     c.load_items = A.load_items; c.n_load_items = A.n_load_items; c.load_nrec = A.load_nrec; c.load_ncell = A.load_ncell;
-    c.split_bn = false; c.units = A.units + (uint64_t)p * A.unit_stride * 4; c.consts_mont = A.consts_mont; c.bn_perm_cells = A.bn_perm_cells;
+    c.split_bn = false;
     return c;
 }
 
 // Register budget of the strand kernels (the attribute propagates to their callees): H2W_QUAD_WAVES wavefronts per SIMD.
-#ifndef H2W_QUAD_WAVES
-#define H2W_QUAD_WAVES 1
-#endif
-#define H2W_WAVES __attribute__((amdgpu_waves_per_eu(H2W_QUAD_WAVES, H2W_QUAD_WAVES)))
+#define H2W_WAVES __attribute__((amdgpu_waves_per_eu(1, 1)))
+// the PoseidonBN254 chain kernel: two blocks of QUAD_BLOCK threads per CU by LDS (32.9 KB of tables + 10 KB of value slots per wavefront)
+#define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_prologue(BatchArgs A) {
     typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,32 +143,14 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_coop(Batc
 }
 
 // PoseidonBN254 Merkle chain strands (hash_mode 1): four lanes per (proof, query, kind); blockIdx.y = kind slot
-template <bool COLS> __device__ void glue_lane(const BatchArgs &A, int idx) {
-    typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;   // FriChip::verify_query_round minus its Merkle proofs: one lane per (proof, query)
-    const int nq = A.shape.num_queries;
-    const int p = idx / nq, q = idx % nq;
-    if (!own_unit(A, p, q)) return;
-    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
-    sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
-    DevB be(sink, make_cfg(A, p), true);
-    Verifier<DevB> V(be, A.shape, A.consts);
-    V.query_round(q, *reinterpret_cast<const ChallengeBlock<DevB> *>(&A.cbs[p]));
-    if (be.status) atomicCAS(&A.status[p], 0u, be.status);
-}
-template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_merkle_bn_quad(BatchArgs A) {
+template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void k_merkle_bn_quad(BatchArgs A) {
     typedef QuadSinkT<COLS> QuadSink; typedef ValBackend<QuadSink> QuadB;
-    __builtin_amdgcn_s_setprio(3);
+    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);      // (block-wide barrier inside: before any wavefront leaves)
     const int nq = A.shape.num_queries, total = A.nproofs * nq;
-    if ((int)blockIdx.y == A.role_base) {               // last y slot: the query glue strands, one lane each
-        const int gi = blockIdx.x * QUAD_BLOCK + threadIdx.x;
-        if (gi < total && !(A.dbg_skip_perm & 8)) glue_lane<COLS>(A, gi);
-        return;
-    }
-    stage_bn_consts(threadIdx.x, QUAD_BLOCK);
     if (A.dbg_skip_perm & 16) return;
     if ((int)((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63)) >> 2) >= total) return;      // a wavefront past the last strand
     int idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
-    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes): keeps shuffles in-quad valid
+    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes)
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
     if (!own_unit(A, p, q)) return;                     // quad-uniform
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
@@ -194,173 +171,22 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_WAVES void k_m
     if ((threadIdx.x & 3) == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
-// blockIdx.y = 0: query glue ; 1 + kind: merkle strand `kind`
+// query glue strands (FriChip::verify_query_round minus its Merkle proofs, fri/mod.rs:338-444): one lane per (proof, query)
 template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_strands(BatchArgs A) {
     typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
     __builtin_amdgcn_s_setprio(3);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = A.shape.num_queries;
     if (idx >= A.nproofs * nq) return;
-    const int p = idx / nq, q = idx % nq, role = A.role_base + blockIdx.y, sq = q == 0 ? 0 : 1;
+    const int p = idx / nq, q = idx % nq;
     if (!own_unit(A, p, q)) return;
-    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;   // initial oracles
     DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
     const ChallengeBlock<DevB> &cb = *reinterpret_cast<const ChallengeBlock<DevB> *>(&A.cbs[p]);
-    if (role == 0) {
-        DevB be(sink, make_cfg(A, p), true);
-        Verifier<DevB> V(be, A.shape, A.consts);
-        V.query_round(q, cb);
-        if (be.status) atomicCAS(&A.status[p], 0u, be.status);
-        return;
-    }
-    const int kind = role <= n_or ? role - 1 : 3 + (role - 1 - n_or);   // roles 1..n_or: initial oracles; then fold steps
-    sink.nrec += A.st.mk_rec_rel[sq][kind]; sink.cell_off += A.st.mk_cell_rel[sq][kind];
-    ValCfg mc = make_cfg(A, p); mc.split_bn = true;
-    DevB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
-    be.unit_idx = strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind];
+    DevB be(sink, make_cfg(A, p), true);
     Verifier<DevB> V(be, A.shape, A.consts);
-    // index bits of this strand (fri/mod.rs:363-369, 407-408), from the query-index challenge value
-    const uint64_t x = cb.fri_query_indices[q];
-    const int lde = V.d.lde_bits; int lo = 0;
-    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
-    uint64_t bits[64]; const int nb = lde - lo;
-    for (int i = 0; i < nb; i++) bits[i] = (x >> (lo + i)) & 1;
-    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
-    V.merkle_strand(q, kind, bits, nb, cap_index);
+    V.query_round(q, cb);
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
-}
-
-// PoseidonBN254 permutation units: one lane per permutation (all independent once the chain strands have stored
-// their input states).  Hand-scheduled restatement of hash/poseidon_bn254/permutation.rs:48-203 that emits the
-// 4,032 cells in the chip's order.  Arithmetic is "hybrid": the state stays CANONICAL (cells are canonical), a
-// constant*variable product is one Montgomery product with the constant pre-multiplied by R, and x^5 takes five
-// (X = x*R; x2 = x*X/R; X2 = X*X/R; x4 = x2*X2/R; x5 = x4*X/R) -> 960 Montgomery products per permutation
-// instead of 2 x 784.  Constants are wave-uniform (scalar loads).
-// Stores: STAGED = true stages BN_CH cells per lane in LDS ([cell][lane], rows padded by 32 B) and lets the wavefront
-// flush them as whole 128-B lines (4 permutations x 512 contiguous bytes per store instruction) instead of 64 scattered
-// 32-byte stores; all lanes of the wave are in lockstep (same cell count), which the one odd unit with the cached
-// load_zero cell would break, so that unit runs in its own launch with STAGED = false.
-constexpr int BN_CH = 8;
-constexpr int BN_ROW = 64 * 32 + 32;   // bytes per staged cell row
-// One out-of-line copy of the Montgomery product (arguments and result in VGPRs, by value): the unit kernel has ~25 call
-// sites and must stay inside the 64 KB instruction cache (fully inlined it was ~400 KB and ran instruction-fetch bound).
-__device__ __attribute__((noinline)) void bn_flush(const char *lds, unsigned long long mydst, int lane) {
-    typedef unsigned long long ull; struct __attribute__((aligned(16))) q16 { ull x, y; };
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 2
-    for (int it = 0; it < 16; it++) {   // per store instruction: 4 permutations x 256 contiguous bytes (8 cells)
-        const int P = it * 4 + (lane >> 4), k = (lane & 15) >> 1, h = lane & 1;
-        const unsigned long long d = __shfl(mydst, P, 64);
-#pragma unroll
-        for (int kk = 0; kk < BN_CH; kk += 8) {
-            const q16 v0 = *reinterpret_cast<const q16 *>(lds + (k + kk) * BN_ROW + P * 32 + h * 16);
-            unsigned long long *g = reinterpret_cast<unsigned long long *>(d + (unsigned long long)((k + kk) * 32 + h * 16));
-            H2W_GSTORE64(g, v0.x); H2W_GSTORE64(g + 1, v0.y);
-        }
-    }
-}
-template <bool STAGED> struct BnEmit {
-    fr_t *out; uint64_t ninv; fr_t r2;
-    char *lds; int lane, cnt;
-    __device__ __forceinline__ void flush() { bn_flush(lds, (unsigned long long)out, lane); out += BN_CH; cnt = 0; }
-    __device__ __forceinline__ void put(const fr_t &v) {
-        if (STAGED) { *reinterpret_cast<fr_t *>(lds + cnt * BN_ROW + lane * 32) = v; if (++cnt == BN_CH) flush(); }
-        else *out++ = v;
-    }
-    __device__ __forceinline__ void put64(uint64_t v) { fr_t t = fr_from_u64(v); put(t); }
-    __device__ __forceinline__ fr_t exp5(const fr_t &x) {
-        const fr_t X = mont_call(x, r2, ninv);
-        const fr_t x2 = mont_call(x, X, ninv), X2 = mont_call(X, X, ninv);
-        const fr_t x4 = mont_call(x2, X2, ninv), x5 = mont_call(x4, X, ninv);
-        put64(0); put(x); put(x); put(x2);
-        put64(0); put(x2); put(x2); put(x4);
-        put64(0); put(x4); put(x); put(x5);
-        return x5;
-    }
-    __device__ __forceinline__ void ark(fr_t *s, int it) {
-        for (int i = 0; i < 4; i++) { const fr_t c = c_bn[0].c[it + i]; put(c); put(s[i]); put(c); put64(1); s[i] = fr_add(s[i], c); put(s[i]); }
-    }
-    __device__ __forceinline__ fr_t mul_add(const fr_t &c, const fr_t &cm, const fr_t &x, const fr_t &acc) {   // [acc, c, x, c*x+acc]
-        const fr_t v = fr_add(mont_call(x, cm, ninv), acc);
-        put(acc); put(c); put(x); put(v);
-        return v;
-    }
-    __device__ __forceinline__ void mix(fr_t *s, const h2w_fr_t (*mc)[4], const h2w_fr_t (*mm)[4], bool &zero_cached) {
-        if (!zero_cached) { put64(0); zero_cached = true; }
-        fr_t ns[4];
-        for (int i = 0; i < 4; i++) {
-            fr_t acc = fr_zero();
-            for (int j = 0; j < 4; j++) acc = mul_add(mc[j][i], mm[j][i], s[j], acc);
-            ns[i] = acc;
-        }
-        for (int i = 0; i < 4; i++) s[i] = ns[i];
-    }
-    __device__ __forceinline__ void permute(fr_t *s, bool zero_cached) {
-        ark(s, 0);
-        for (int half = 0; half < 2; half++) {
-            if (half == 1) {   // partial rounds (:83-110)
-                for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-                    s[0] = exp5(s[0]);
-                    const fr_t c = c_bn[0].c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r];
-                    put(c); put(s[0]); put(c); put64(1); s[0] = fr_add(s[0], c); put(s[0]);
-                    fr_t ns0 = fr_zero();
-                    for (int j = 0; j < 4; j++) { const int ix = (BN_WIDTH * 2 - 1) * r + j; put(c_bn[0].s[ix]); ns0 = mul_add(c_bn[0].s[ix], c_bn[1].s[ix], s[j], ns0); }
-                    for (int kk = 1; kk < 4; kk++) { const int ix = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1; put(c_bn[0].s[ix]); s[kk] = mul_add(c_bn[0].s[ix], c_bn[1].s[ix], s[0], s[kk]); }
-                    s[0] = ns0;
-                }
-            }
-            // full_rounds(is_first = half == 0) (:112-160)
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(c_bn[0].m[i][j]);
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) put(c_bn[0].p[i][j]);
-            for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
-                for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
-                ark(s, half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
-                mix(s, c_bn[0].m, c_bn[1].m, zero_cached);
-            }
-            for (int i = 0; i < 4; i++) s[i] = exp5(s[i]);
-            if (half == 0) { ark(s, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(s, c_bn[0].p, c_bn[1].p, zero_cached); }
-            else mix(s, c_bn[0].m, c_bn[1].m, zero_cached);
-        }
-    }
-};
-// grid: every (proof, unit) except the one unit per proof that carries the Context's first load_zero cell
-__global__ __launch_bounds__(64) void k_bn_units(BatchArgs A) {
-    __shared__ __attribute__((aligned(16))) char s_stage[BN_CH * BN_ROW];
-    const uint64_t nu = A.st.total_unit, nreg = A.st.first_zero_unit >= 0 ? nu - 1 : nu;
-    const uint64_t total = nreg * (uint64_t)A.nproofs;
-    const uint64_t zblocks = A.st.first_zero_unit >= 0 ? ((uint64_t)A.nproofs + 63) / 64 : 0;
-    if (blockIdx.x < zblocks) {   // leading blocks (dispatched first: they are the slowest): the odd unit (4,033 cells) of each proof, direct stores
-        const uint64_t zp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (zp < (uint64_t)A.nproofs && A.st.first_zero_unit >= 0) {
-            const uint64_t uz = (uint64_t)A.st.first_zero_unit;
-            BnEmit<false> Z; Z.out = A.out + zp * A.cell_stride + A.unit_cell[uz]; Z.ninv = A.P.ninv; Z.r2 = A.P.r2; Z.lds = nullptr; Z.lane = 0; Z.cnt = 0;
-            fr_t zs[4]; const fr_t *zin = A.units + (zp * A.unit_stride + uz) * 4;
-            for (int i = 0; i < 4; i++) zs[i] = zin[i];
-            Z.permute(zs, false);
-        }
-        return;
-    }
-    uint64_t idx = ((uint64_t)blockIdx.x - zblocks) * blockDim.x + threadIdx.x;
-    if (idx >= total) idx = total - 1;                 // tail lanes redo the last unit (identical bytes) to keep the wave in lockstep
-    const int p = (int)(idx / nreg); uint64_t u = idx % nreg;
-    if (A.st.first_zero_unit >= 0 && u >= (uint64_t)A.st.first_zero_unit) u++;
-    BnEmit<true> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.ninv = A.P.ninv; E.r2 = A.P.r2;
-    E.lds = s_stage; E.lane = threadIdx.x; E.cnt = 0;
-    fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
-    for (int i = 0; i < 4; i++) st[i] = in[i];
-    E.permute(st, true);
-}
-// the odd unit (4,033 cells): one lane per proof, direct stores
-__global__ __launch_bounds__(64) void k_bn_unit_zero(BatchArgs A) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.nproofs || A.st.first_zero_unit < 0) return;
-    const uint64_t u = (uint64_t)A.st.first_zero_unit;
-    BnEmit<false> E; E.out = A.out + (uint64_t)p * A.cell_stride + A.unit_cell[u]; E.ninv = A.P.ninv; E.r2 = A.P.r2;
-    E.lds = nullptr; E.lane = 0; E.cnt = 0;
-    fr_t st[4]; const fr_t *in = A.units + ((uint64_t)p * A.unit_stride + u) * 4;
-    for (int i = 0; i < 4; i++) st[i] = in[i];
-    E.permute(st, false);
 }
 
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
@@ -383,16 +209,15 @@ struct h2w_plan {
     Derived d; ProofLayout pl;
     uint64_t nrec = 0, ncells = 0, rec_cells = 0;
     LoadItem *d_items = nullptr; uint32_t n_items = 0; uint64_t load_nrec = 0, load_ncell = 0;
-    BnConsts h_bn[2];
     h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
-    uint64_t *d_unit_cell = nullptr; h2w_poseidon_consts_t *d_consts_mont = nullptr; uint64_t nunit = 0;
+    fr_t *d_bn_tab = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
-    static constexpr int EV_RING = 64;
-    hipEvent_t evr[EV_RING][5];
-    bool fifo_emit = false;   // H2W_FIFO_EMIT=1: serialise the emit phases of successive calls (diagnostic)
-    hipEvent_t t_done; bool t_done_valid = false;   // end of the previous call's emit phase (any stream): emit phases run FIFO
+    static constexpr int EV_RING = 64, N_EV = 8, N_SIDE = 16;
+    hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 2 glue (+ Goldilocks Merkle strands) done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call
+    hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
+    bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
 };
@@ -411,7 +236,6 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     }
     h2w_plan *pl = new h2w_plan(s.lookup_bits);
     pl->shape = s; pl->device = device_id; pl->P = fr_params_init(); pl->h_consts = *consts;
-    { const char *e = getenv("H2W_FIFO_EMIT"); pl->fifo_emit = e && e[0] == '1'; }
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
     if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
     memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1; pl->st.first_zero_unit = -1;
@@ -424,7 +248,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     {
         PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st; sink.unit_cell = &unit_cell; sink.items = &items;
         ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = s.hash_mode; cfg.L = s.lookup_bits; cfg.P = pl->P;
-        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.units = nullptr; cfg.consts_mont = nullptr; cfg.bn_perm_cells = 0; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
+        cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
         ValBackend<PlanSink> be(sink, cfg, false);
         Verifier<ValBackend<PlanSink>> V(be, pl->shape, consts);
         ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
@@ -463,21 +287,10 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             H2W_HIP(hipMalloc((void **)&pl->d_items, items.size() * sizeof(LoadItem)));
             H2W_HIP(hipMemcpy(pl->d_items, items.data(), items.size() * sizeof(LoadItem), hipMemcpyHostToDevice));
         }
-        if (!unit_cell.empty()) {
-            H2W_HIP(hipMalloc((void **)&pl->d_unit_cell, unit_cell.size() * sizeof(uint64_t)));
-            H2W_HIP(hipMemcpy(pl->d_unit_cell, unit_cell.data(), unit_cell.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        }
-        {   // constants in Montgomery form for the value-domain BN254 Poseidon
-            h2w_poseidon_consts_t *km = new h2w_poseidon_consts_t(*consts);
-            for (int i = 0; i < 88; i++) km->bn_c[i] = fr_mont_mul(consts->bn_c[i], pl->P.r2, pl->P.ninv);
-            for (int i = 0; i < 392; i++) km->bn_s[i] = fr_mont_mul(consts->bn_s[i], pl->P.r2, pl->P.ninv);
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { km->bn_m[i][j] = fr_mont_mul(consts->bn_m[i][j], pl->P.r2, pl->P.ninv); km->bn_p[i][j] = fr_mont_mul(consts->bn_p[i][j], pl->P.r2, pl->P.ninv); }
-            memcpy(pl->h_bn[0].c, consts->bn_c, sizeof(consts->bn_c)); memcpy(pl->h_bn[0].s, consts->bn_s, sizeof(consts->bn_s)); memcpy(pl->h_bn[0].m, consts->bn_m, sizeof(consts->bn_m)); memcpy(pl->h_bn[0].p, consts->bn_p, sizeof(consts->bn_p));
-            memcpy(pl->h_bn[1].c, km->bn_c, sizeof(km->bn_c)); memcpy(pl->h_bn[1].s, km->bn_s, sizeof(km->bn_s)); memcpy(pl->h_bn[1].m, km->bn_m, sizeof(km->bn_m)); memcpy(pl->h_bn[1].p, km->bn_p, sizeof(km->bn_p));
-            hipError_t e1 = hipMalloc((void **)&pl->d_consts_mont, sizeof(h2w_poseidon_consts_t));
-            hipError_t e2 = e1 == hipSuccess ? hipMemcpy(pl->d_consts_mont, km, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice) : e1;
-            delete km;
-            H2W_HIP(e2);
+        {   // PoseidonBN254 tables: canonical and R-premultiplied, per plan (two plans with different tables never share state)
+            std::vector<fr_t> tab(2 * BK_T); bn_table_build(*consts, pl->P, tab.data());
+            H2W_HIP(hipMalloc((void **)&pl->d_bn_tab, tab.size() * sizeof(fr_t)));
+            H2W_HIP(hipMemcpy(pl->d_bn_tab, tab.data(), tab.size() * sizeof(fr_t), hipMemcpyHostToDevice));
         }
         H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t)));
         H2W_HIP(hipMemcpy(pl->d_consts, consts, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
@@ -486,8 +299,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         H2W_HIP(hipMemcpy(pl->d_ncells, nc.data(), nc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         H2W_HIP(hipMalloc((void **)&pl->d_inv, inv.size() * sizeof(fr_t)));
         H2W_HIP(hipMemcpy(pl->d_inv, inv.data(), inv.size() * sizeof(fr_t), hipMemcpyHostToDevice));
-        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
-        H2W_HIP(hipEventCreateWithFlags(&pl->t_done, hipEventDisableTiming));
+        for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < h2w_plan::N_EV; i++) H2W_HIP(hipEventCreate(&pl->evr[r][i]));
         pl->ev_ready = true;
         return 0;
     };
@@ -496,19 +308,17 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
 }
 void h2w_plan_free(h2w_plan *p) {
     if (!p) return;
-    if (g_const_owner == (const void *)p) g_const_owner = nullptr;
     if (p->d_meta) (void)hipFree(p->d_meta);
-    if (p->d_unit_cell) (void)hipFree(p->d_unit_cell);
     if (p->d_items) (void)hipFree(p->d_items);
-    if (p->d_consts_mont) (void)hipFree(p->d_consts_mont);
+    if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->d_lookup_cells) (void)hipFree(p->d_lookup_cells);
     if (p->d_sel_bits) (void)hipFree(p->d_sel_bits);
     if (p->d_col_tab) (void)hipFree(p->d_col_tab);
-    if (p->ev_ready) (void)hipEventDestroy(p->t_done);
-    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->evr[r][i]);
+    if (p->ev_ready) for (int r = 0; r < h2w_plan::EV_RING; r++) for (int i = 0; i < h2w_plan::N_EV; i++) (void)hipEventDestroy(p->evr[r][i]);
+    for (int i = 0; i < p->n_side; i++) (void)hipStreamDestroy(p->side[i]);
     p->dt.free();
     delete p;
 }
@@ -521,7 +331,7 @@ static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_c
     o_recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
     o_cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
     o_status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
-    o_units = o; o += align_up((size_t)n * p->nunit * 4 * sizeof(fr_t), 256);
+    o_units = o;
     o += align_up((size_t)n * sizeof(uint32_t), 256);      // expansion kernel's per-proof tile counters (last region)
     total = o;
 }
@@ -594,83 +404,68 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
     A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm; A.shard_rank = shard_rank; A.shard_world = shard_world;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
-    A.units = (fr_t *)(ws + o_units); A.unit_stride = p->nunit; A.consts_mont = p->d_consts_mont; A.unit_cell = p->d_unit_cell;
-    A.bn_perm_cells = 4032; A.role_base = 0;
+    A.bn_tab = p->d_bn_tab; A.role_base = 0;
     A.dbg_skip_perm = 0;
 #ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/): never defined in the product build, the results are garbage
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e ? atoi(e) : 0; } A.dbg_skip_perm = dbg; }
 #endif
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
-    p->ev = p->evr[p->n_batches % h2w_plan::EV_RING]; p->n_batches++;
-    H2W_HIP(hipEventRecord(p->ev[0], stream));
+    p->ev = p->evr[p->n_batches % h2w_plan::EV_RING];
+    hipStream_t cstream = stream;      // chain kernel's stream
+    if (p->fork_chains && p->shape.hash_mode == 1) {
+        int k = 0; while (k < p->n_side && p->side_of[k] != stream) k++;
+        if (k == p->n_side && p->n_side < h2w_plan::N_SIDE) { H2W_HIP(hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking)); p->side_of[k] = stream; p->n_side++; }
+        if (k < p->n_side) cstream = p->side[k];      // (more caller streams than side streams: the extra ones do not fork)
+    }
+    p->n_batches++;
+    hipEvent_t *ev = p->ev;
     int dbg_skip = 0;
-#ifdef H2W_DEBUG_HOOKS   // H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion; H2W_DBG_SKIP_ALT="a,b": even calls mask a, odd calls mask b
-    {
-        static int env_skip = -1, alt_a = -1, alt_b = -1; static uint64_t call_no = 0;
-        if (env_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); env_skip = e ? atoi(e) : 0; }
-        if (alt_a == -1) { const char *e = getenv("H2W_DBG_SKIP_ALT"); if (!(e && sscanf(e, "%d,%d", &alt_a, &alt_b) == 2)) alt_a = -2; }
-        dbg_skip = alt_a >= 0 ? ((call_no++ & 1) ? alt_b : alt_a) : env_skip;
-    }
+#ifdef H2W_DEBUG_HOOKS   // H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion (timing experiments only: the results are garbage)
+    { static int env_skip = -1; if (env_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); env_skip = e ? atoi(e) : 0; } dbg_skip = env_skip; }
 #endif
+    H2W_HIP(hipEventRecord(ev[0], stream));
+    // 1. prologue strands: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks
     if (!(dbg_skip & 1)) { if (cm.starts) hipLaunchKernelGGL(k_prologue_coop<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_coop<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); }
-    H2W_HIP(hipEventRecord(p->ev[3], stream));
+    H2W_HIP(hipEventRecord(ev[1], stream));
     const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
-    // roles: 0 = query glue, then one role per merkle strand kind (initial oracles, fold steps)
-    if (p->shape.hash_mode == 0) {   // Goldilocks-Poseidon Merkle: glue lanes + one cooperating wavefront per Merkle strand
-        if (cm.starts) {
-            hipLaunchKernelGGL(k_strands<true>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
-            hipLaunchKernelGGL(k_merkle_gl_coop<true>, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
-        } else {
-            hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
-            hipLaunchKernelGGL(k_merkle_gl_coop<false>, dim3(nlanes, (unsigned)(p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
-        }
-    } else {
-        if (g_const_owner != (const void *)p) {   // (re)load the constant-memory BN254 tables for this plan, ordered on `stream`
-            H2W_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_bn), p->h_bn, sizeof(p->h_bn), 0, hipMemcpyHostToDevice, stream));
-            g_const_owner = (const void *)p;
-        }
-        static int two_pass = -1;
-        if (two_pass < 0) { const char *e = getenv("H2W_BN_UNITS"); two_pass = e && e[0] == '1'; }
-        if (two_pass && cm.starts) { set_error("column-major emission is not available on the H2W_BN_UNITS=1 A/B path"); return -1; }
-        if (!two_pass) {
-            // PoseidonBN254 Merkle chain strands (4 lanes each) emit their permutations' cells themselves; extra y slot: query glue
-            A.role_base = p->d.n_oracles + p->d.n_steps;
-            // LDS padding (dynamic, unused): 32 KB staging + pad caps the kernel at 4 wavefronts per CU, so the remaining LDS can hold
-            // blocks of another batch's expansion kernel instead of a fifth chain wavefront (env override for A/B)
-            static int pad = -1; if (pad < 0) { const char *e = getenv("H2W_QUAD_PAD_LDS"); pad = e ? atoi(e) : 0; }
-            const dim3 qgrid((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, (unsigned)(p->d.n_oracles + p->d.n_steps + 1));
-            if (!(dbg_skip & 2)) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_quad<true>, qgrid, dim3(QUAD_BLOCK), (size_t)pad, stream, A); else hipLaunchKernelGGL(k_merkle_bn_quad<false>, qgrid, dim3(QUAD_BLOCK), (size_t)pad, stream, A); }
-            H2W_HIP(hipEventRecord(p->ev[4], stream));
-        } else {
-            // A/B path (H2W_BN_UNITS=1): one lane per chain stores every permutation's input state as a unit, a second kernel
-            // (one lane per permutation) re-evaluates the units and emits their cells
-            A.role_base = 0;
-            hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, (unsigned)(1 + p->d.n_oracles + p->d.n_steps)), dim3(64), 0, stream, A);
-            H2W_HIP(hipEventRecord(p->ev[4], stream));
-            const uint64_t nreg = (p->st.first_zero_unit >= 0 ? p->nunit - 1 : p->nunit) * n_proofs;
-            const uint64_t zblocks = p->st.first_zero_unit >= 0 ? (n_proofs + 63) / 64 : 0;
-            if (nreg) hipLaunchKernelGGL(k_bn_units, dim3((unsigned)((nreg + 63) / 64 + zblocks)), dim3(64), 0, stream, A);
+    const unsigned nkinds = (unsigned)(p->d.n_oracles + p->d.n_steps);
+    // 2. PoseidonBN254 Merkle chain strands (hash_mode 1): four lanes per (proof, query, tree); they emit their permutations' cells
+    //    themselves and write no block records, so nothing but the prologue orders them against the glue strands and the expansion
+    //    kernel of the same batch: they run on a side stream of the plan and rejoin at the end of the call.
+    if (p->shape.hash_mode == 1) {
+        if (cstream != stream) H2W_HIP(hipStreamWaitEvent(cstream, ev[1], 0));
+        H2W_HIP(hipEventRecord(ev[4], cstream));
+        const dim3 qgrid((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, nkinds);
+        if (!(dbg_skip & 2)) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_quad<true>, qgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_quad<false>, qgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
+        H2W_HIP(hipEventRecord(ev[5], cstream));
+    }
+    // 3. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per (proof, query);
+    //    Goldilocks-Poseidon Merkle strands (hash_mode 0): one cooperating wavefront per (proof, query, tree) - these do write records
+    if (!(dbg_skip & 2)) {
+        if (cm.starts) hipLaunchKernelGGL(k_strands<true>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+        if (p->shape.hash_mode == 0) {
+            if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_coop<true>, dim3(nlanes, nkinds), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_merkle_gl_coop<false>, dim3(nlanes, nkinds), dim3(64), 0, stream, A);
         }
     }
-    if (p->shape.hash_mode == 0) H2W_HIP(hipEventRecord(p->ev[4], stream));
-    H2W_HIP(hipEventRecord(p->ev[1], stream));
-    if (p->fifo_emit && p->shape.hash_mode == 0 && p->t_done_valid) H2W_HIP(hipStreamWaitEvent(stream, p->t_done, 0));
+    H2W_HIP(hipEventRecord(ev[2], stream));
+    if (p->shape.hash_mode == 0) { H2W_HIP(hipEventRecord(ev[4], stream)); H2W_HIP(hipEventRecord(ev[5], stream)); }
+    // 4. expansion of the block records (HBM-write-bound)
     ExpandArgs E;
     E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
     E.shard_rank = (uint32_t)shard_rank; E.shard_world = (uint32_t)shard_world; E.nq = (uint32_t)p->shape.num_queries;
     E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
     if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
-    p->dt.fill(E); E.rb = p->tt.rb;
-    static int dyn_tiles = -1; if (dyn_tiles < 0) { const char *e = getenv("H2W_EXPAND_STATIC_TILES"); dyn_tiles = !(e && e[0] == '1'); }
-    E.tile_ctr = dyn_tiles ? (uint32_t *)(ws + ws_ctr_offset(n_proofs, total)) : nullptr;
-    if (E.tile_ctr) H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
+    p->dt.fill(E);
+    E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
+    H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
-    if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, p->ev[1], 0));    // value strands done -> expansion on the emit stream
+    if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, ev[2], 0));    // value strands done -> expansion on the emit stream
     if (!(dbg_skip & 4)) launch_expand(E, n_proofs, gx, estream);
-    H2W_HIP(hipEventRecord(p->ev[2], estream));
-    if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, p->ev[2], 0));    // the caller's stream completes when the advice is complete
-    H2W_HIP(hipEventRecord(p->t_done, estream)); p->t_done_valid = true;
+    H2W_HIP(hipEventRecord(ev[3], estream));
+    if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, ev[3], 0));    // the caller's stream completes when the advice is complete
+    if (p->shape.hash_mode == 1 && cstream != stream) H2W_HIP(hipStreamWaitEvent(stream, ev[5], 0));
+    H2W_HIP(hipEventRecord(ev[6], stream));
     p->ev_recorded = true;
     H2W_HIP(hipGetLastError());
     return 0;
@@ -690,7 +485,7 @@ int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, voi
     E.shard_rank = 0; E.shard_world = 1; E.nq = (uint32_t)p->shape.num_queries;
     E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
     if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
-    p->dt.fill(E); E.rb = p->tt.rb;
+    p->dt.fill(E);
     E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
     H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), stream));
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
@@ -710,7 +505,7 @@ int h2w_plan_metadata(h2w_plan *pl) {
     PlanSink sink; sink.meta = nullptr; sink.tt = &pl->tt; sink.st = &st; sink.unit_cell = &unit_cell; sink.items = &items;
     sink.sel_bits = &pl->sel_bits; sink.lk_bits = &pl->lk_bits;
     ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = pl->shape.hash_mode; cfg.L = pl->shape.lookup_bits; cfg.P = pl->P;
-    cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.units = nullptr; cfg.consts_mont = nullptr; cfg.bn_perm_cells = 0; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
+    cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
     ValBackend<PlanSink> be(sink, cfg, false);
     Verifier<ValBackend<PlanSink>> V(be, pl->shape, &pl->h_consts);
     ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
@@ -934,14 +729,19 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream_) {
 int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batches before the last one (ring of 64)
     if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing: no such batch"); return -1; }
     hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
-    H2W_HIP(hipEventSynchronize(ev[2]));
-    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[3]));   // prologue strands
-    H2W_HIP(hipEventElapsedTime(&ms[1], ev[3], ev[4]));   // query + Merkle strands
-    H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[1]));   // BN254 permutation-unit emission (0 for GL-Poseidon Merkle)
-    H2W_HIP(hipEventElapsedTime(&ms[3], ev[1], ev[2]));   // expansion kernel
-    H2W_HIP(hipEventElapsedTime(&ms[4], ev[0], ev[2]));   // whole batch
+    H2W_HIP(hipEventSynchronize(ev[6]));
+    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));   // prologue strands
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[1], ev[2]));   // query glue strands (+ Goldilocks-Poseidon Merkle strands)
+    H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[5]));   // PoseidonBN254 Merkle chain kernel (on its side stream; 0 for Goldilocks-Poseidon Merkle)
+    H2W_HIP(hipEventElapsedTime(&ms[3], ev[2], ev[3]));   // expansion kernel
+    H2W_HIP(hipEventElapsedTime(&ms[4], ev[0], ev[6]));   // whole call
     return 0;
 }
 int h2w_plan_last_timing(h2w_plan *p, float ms[5]) { return h2w_plan_timing(p, 0, ms); }
+int h2w_plan_configure(h2w_plan *p, int option, int value) {
+    if (!p) { set_error("h2w_plan_configure: null plan"); return -1; }
+    if (option == H2W_OPT_FORK_CHAINS) { p->fork_chains = value != 0; return 0; }
+    set_error("h2w_plan_configure: unknown option"); return -1;
+}
 
 }  // extern "C"

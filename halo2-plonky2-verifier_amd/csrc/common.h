@@ -23,7 +23,7 @@ struct ExpandArgs {
     const uint32_t *slots; uint32_t nslots;
     const tmpl_info_t *info; uint32_t ntmpl;
     const fr_t *consts; uint32_t nconsts;
-    int rb;
+    int rb, lookup_bits;
     uint32_t max_cells;        // largest template (cells per record) of the plan: sizes expand_kernel_h's chunk table
     uint32_t *tile_ctr;        // [nproofs] zeroed work counters: tiles are handed out dynamically (null: static striding)
     ColMap cm;                 // column-major emission (starts == nullptr: flat)
@@ -38,9 +38,10 @@ constexpr int MAX_CONSTS = 96;
 // device copies of a TemplateTable
 struct DeviceTables {
     uint32_t *slots = nullptr; tmpl_info_t *info = nullptr; fr_t *consts = nullptr;
-    uint32_t nslots = 0, ntmpl = 0, nconsts = 0, max_cells = 0;
+    uint32_t nslots = 0, ntmpl = 0, nconsts = 0, max_cells = 0; int rb = 0, L = 0;
     int upload(const TemplateTable &tt) {
         free();
+        rb = tt.rb; L = tt.L;
         max_cells = 0; for (const tmpl_info_t &ti : tt.info) if (ti.ncells > max_cells) max_cells = ti.ncells;
         if (tt.slots.size() > MAX_SLOTS || tt.consts.size() > MAX_CONSTS || tt.info.size() > T_MAX) { set_error("template table too large"); return -1; }
         nslots = (uint32_t)tt.slots.size(); ntmpl = (uint32_t)tt.info.size(); nconsts = (uint32_t)tt.consts.size();
@@ -52,7 +53,7 @@ struct DeviceTables {
         if (nconsts) H2W_HIP(hipMemcpy(consts, tt.consts.data(), nconsts * sizeof(fr_t), hipMemcpyHostToDevice));
         return 0;
     }
-    void fill(ExpandArgs &A) const { A.slots = slots; A.nslots = nslots; A.info = info; A.ntmpl = ntmpl; A.consts = consts; A.nconsts = nconsts; A.max_cells = max_cells; }
+    void fill(ExpandArgs &A) const { A.slots = slots; A.nslots = nslots; A.info = info; A.ntmpl = ntmpl; A.consts = consts; A.nconsts = nconsts; A.max_cells = max_cells; A.rb = rb; A.lookup_bits = L; }
     void free() {
         if (slots) hipFree(slots); if (info) hipFree(info); if (consts) hipFree(consts);
         slots = nullptr; info = nullptr; consts = nullptr;

@@ -11,13 +11,6 @@
 
 namespace h2w {
 
-// PoseidonBN254 constants for the unit kernel, canonical [0] and Montgomery form [1], in CONSTANT address space:
-// wave-uniform reads become scalar loads (lgkmcnt), which — unlike vector loads — do not queue behind the kernel's own
-// outstanding cell stores on vmcnt.  One table per device context; re-uploaded on the stream when a plan with
-// different constants runs (g_const_owner).
-struct BnConsts { h2w_fr_t c[88], s[392], m[4][4], p[4][4]; };
-__constant__ BnConsts c_bn[2];
-
 constexpr int GLP_RECS_FULL = 12 + 48 + 1 + 12 * 14;           // constant_layer, sbox_layer, mds_layer
 constexpr int GLP_RECS_PARTIAL_ROUND = 4 + 1 + 1 + 11 + 1 + 11; // sbox, +const, d = m00*s0, d chain, zeros, v row
 constexpr int GLP_RECS_PARTIAL = 12 + 1 + 121 + N_PARTIAL_ROUNDS * GLP_RECS_PARTIAL_ROUND;
@@ -59,7 +52,6 @@ template <bool COLS> struct CoopSinkT {
     __device__ __forceinline__ void cell(const fr_t &v) { if (lane_mode ? lane_on : lane == 0) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
-    __device__ bool unit_writer() const { return lane == 0; }
     __device__ int coop_lanes() { return 64; }
     __device__ int coop_lane() { return lane; }
     __device__ uint64_t lane_bcast(uint64_t v, int src) { return __shfl(v, src, 64); }
@@ -73,7 +65,6 @@ template <bool COLS> struct CoopSinkT {
     __device__ void bn_perm_begin(bool) {}
     __device__ void bn_perm_end(bool) {}
     __device__ void note_load(uint64_t, int) {}
-    __device__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
     __device__ bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
     uint32_t load_flag = 0;      // set by coop_load_proof: some word is outside its field's canonical range (status 4)
@@ -211,51 +202,99 @@ template <bool COLS> struct CoopSinkT {
 typedef CoopSinkT<false> CoopSink;
 
 // ---------------------------------------------------------------------------------------------------------------
-// QuadSink: four adjacent lanes execute one BN254 Merkle chain strand quad-uniformly (lane 0 of the quad writes the
-// strand's direct cells) and split the width-4 PoseidonBN254 state between them for the value-domain permutation:
-// full rounds 4-way parallel (x^5, then each lane one output row of the mix), partial rounds: lane 0 does the S-box,
-// all four lanes one product of the sparse row, lanes 1-3 their column update (5 instead of 14 dependent products).
-// Montgomery product as a real call, for code that is not store-bound.  NOT for the quad emitter: every AMDGPU function entry starts
-// with s_waitcnt vmcnt(0), i.e. waits for all cell stores in flight.
-__device__ __attribute__((noinline)) fr_t mont_call(fr_t a, fr_t b, uint64_t ninv) { return fr_mont_mul(a, b, ninv); }
-
-// per-quad LDS staging regions of the BN254 quad emitter (QuadSink::stage / flush): 16 quads x QST cells x 32 B per wavefront
-// (QST 64: 32 KB, five wavefronts per CU by LDS; QST 32: 16 KB, and the 4-lane layers are staged in two passes)
-#ifndef H2W_QST
-#define H2W_QST 64
-#endif
+// QuadSink: four adjacent lanes execute one PoseidonBN254 Merkle chain strand quad-uniformly (lane 0 of the quad writes the
+// strand's few direct cells) and split the width-4 state between them: lane i owns state element i.  The permutation's 4,032
+// cells (hash/poseidon_bn254/permutation.rs:48-203) are emitted by the quad itself while it computes them.
+//
+// Memory behaviour (what the round-1 emitter stalled on, profiles/r01_pmc_issue_*):
+//   * the PoseidonBN254 tables (canonical for the cells and the adds, pre-multiplied by R for the products) are a per-PLAN device
+//     buffer staged into LDS once per block: lane-indexed constant reads are ds_reads (lgkmcnt) and never queue behind the
+//     kernel's own cell stores (loads and stores share vmcnt in order on this family);
+//   * every VALUE of a layer is written to LDS once (a "value slot", 32 B per quad and slot), not once per cell that shows it:
+//     the cells of a layer are a static list of sources (value slot | table entry), and the quad streams them out with all
+//     four lanes writing adjacent 16-byte pieces (64 contiguous bytes per quad and store instruction: the form that streams
+//     at the HBM ceiling, tools/ubench_store2.hip).  A partial round stages 7 values instead of 52 cells;
+//   * quad-local exchanges are DPP moves (quad_perm), not ds_bpermute: no LDS round trip on the dependent chain;
+//   * one wavefront's LDS accesses execute in order, so no barrier or wait separates staging, flushing and re-staging.
+// Arithmetic is "hybrid": canonical state, const * var = ONE Montgomery product with the R-premultiplied constant, x^5 in five
+// products (X = x R; x2 = x X / R; X2 = X X / R; x4 = x2 X2 / R; x5 = x4 X / R); in the partial rounds the lanes without an
+// S-box do their own products inside the S-box's instruction stream (5 wavefront-level products per round).
 #ifndef H2W_QUAD_BLOCK
-#define H2W_QUAD_BLOCK 64
+#define H2W_QUAD_BLOCK 256
 #endif
-#ifndef H2W_BN_LDS
-#define H2W_BN_LDS 0
-#endif
-constexpr int QST = H2W_QST;
-static_assert(QST == 32 || QST == 64, "the emitter stages a 64-cell mix layer whole (QST 64) or in two halves (QST 32)");
-constexpr int QHALVES = QST >= 64 ? 1 : 2;                  // staging passes per 4-lane layer: with QST 32 lanes 0-1 stage and flush first, then lanes 2-3
-constexpr int QUAD_BLOCK = H2W_QUAD_BLOCK;                   // threads per block of k_merkle_bn_quad: 4 wavefronts share one LDS copy of the constants
+constexpr int QUAD_BLOCK = H2W_QUAD_BLOCK;                   // threads per block of k_merkle_bn_quad: its wavefronts share one LDS copy of the tables
+constexpr int QUAD_WAVES = QUAD_BLOCK / 64;
 struct __attribute__((aligned(16))) sq16_t { unsigned long long x, y; };
-__shared__ sq16_t s_quad_stage[(QUAD_BLOCK / 4) * QST * 2];
-// The PoseidonBN254 tables (c_bn[0] canonical for the cells, c_bn[1] pre-multiplied by R for the products) in LDS.  The emitter
-// indexes them by lane; from constant/global memory that is a vector load, and on gfx9-family parts loads and stores share
-// vmcnt in order, so waiting for a constant means waiting for every cell store issued before it (microseconds of HBM write
-// latency per flush).  LDS reads count on lgkmcnt and leave the stores in flight.
-enum { BK_C = 0, BK_S = 88, BK_M = 88 + 392, BK_P = 88 + 392 + 16, BK_N = 88 + 392 + 32 };
-#if H2W_BN_LDS
-__shared__ sq16_t s_bn_k[2 * BK_N * 2];
-__device__ __forceinline__ void stage_bn_consts(int tid, int nthreads) {
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c_bn);
-    for (int i = tid; i < 2 * BK_N * 2; i += nthreads) s_bn_k[i] = sq16_t{src[2 * i], src[2 * i + 1]};
+enum { BK_C = 0, BK_S = 88, BK_M = 88 + 392, BK_P = 88 + 392 + 16, BK_N = 88 + 392 + 32, BK_ZERO = BK_N, BK_ONE = BK_N + 1, BK_T = BK_N + 2 };
+constexpr int BN_NSLOT = 20;                                 // value slots per quad (the widest layer, a full-round mix, stages 4 inputs + 16 partial sums)
+constexpr int BN_SLOT_SQ = 16 * 2;                           // 16-byte units per slot row: 16 quads x 32 B
+__shared__ sq16_t s_bn_tab[2 * BK_T * 2];                    // [form][entry][half]: 32.9 KB
+__shared__ sq16_t s_bn_val[QUAD_WAVES * BN_NSLOT * BN_SLOT_SQ];   // [wavefront][slot][quad][half]: 10 KB per wavefront
+// host: the table a plan uploads (BatchArgs::bn_tab): canonical entries, then the same entries times R, each followed by 0 and 1
+inline void bn_table_build(const h2w_poseidon_consts_t &k, const FrParams &P, fr_t *tab /*[2 * BK_T]*/) {
+    for (int i = 0; i < 88; i++) tab[BK_C + i] = k.bn_c[i];
+    for (int i = 0; i < 392; i++) tab[BK_S + i] = k.bn_s[i];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { tab[BK_M + 4 * i + j] = k.bn_m[i][j]; tab[BK_P + 4 * i + j] = k.bn_p[i][j]; }
+    tab[BK_ZERO] = fr_zero(); tab[BK_ONE] = fr_from_u64(1);
+    for (int i = 0; i < BK_T; i++) tab[BK_T + i] = fr_mont_mul(tab[i], P.r2, P.ninv);
+}
+__device__ __forceinline__ void stage_bn_consts(const fr_t *tab, int tid, int nthreads) {
+    const sq16_t *src = reinterpret_cast<const sq16_t *>(tab);
+    for (int i = tid; i < 2 * BK_T * 2; i += nthreads) { sq16_t v; v.x = H2W_GLOAD64(&src[i].x); v.y = H2W_GLOAD64(&src[i].y); s_bn_tab[i] = v; }
     __syncthreads();
 }
 __device__ __forceinline__ fr_t bnk(int which, int idx) {
-    const sq16_t a = s_bn_k[(which * BK_N + idx) * 2], b = s_bn_k[(which * BK_N + idx) * 2 + 1];
+    const sq16_t a = s_bn_tab[(which * BK_T + idx) * 2], b = s_bn_tab[(which * BK_T + idx) * 2 + 1];
     fr_t r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = b.x; r.l[3] = b.y; return r;
 }
-#else
-__device__ __forceinline__ void stage_bn_consts(int, int) {}
-__device__ __forceinline__ fr_t bnk(int which, int idx) { return c_bn[which].c[idx]; }   // c, s, m, p are contiguous: one flat index (address space stays constant memory)
-#endif
+// quad-local exchanges as DPP moves (quad_perm control: two bits per destination lane)
+template <int CTRL> __device__ __forceinline__ fr_t quad_dpp(const fr_t &v) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned lo = (unsigned)v.l[i], hi = (unsigned)(v.l[i] >> 32);
+        const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, false);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, false);
+        r.l[i] = ((unsigned long long)rhi << 32) | rlo;
+    }
+    return r;
+}
+template <int J> __device__ __forceinline__ fr_t quad_bcast(const fr_t &v) { return quad_dpp<J * 0x55>(v); }      // every lane <- lane J of its quad
+__device__ __forceinline__ fr_t quad_up1(const fr_t &v) { return quad_dpp<0x90>(v); }                            // lane i <- lane i - 1 (lane 0 keeps its own)
+__device__ __forceinline__ fr_t quad_up2(const fr_t &v) { return quad_dpp<0x44>(v); }                            // lanes 2, 3 <- lanes 0, 1
+
+// one cell source of a layer: a value slot of the quad, a table entry, or a table entry relative to one of two per-layer bases
+struct BnSrc { int kind, idx; };                              // kind 0: value slot; 1: table entry; 2: entry base A + idx; 3: entry base B + idx
+constexpr BnSrc bV(int s) { return BnSrc{0, s}; }
+constexpr BnSrc bK(int i) { return BnSrc{1, i}; }
+constexpr BnSrc bA(int o) { return BnSrc{2, o}; }
+constexpr BnSrc bB(int o) { return BnSrc{3, o}; }
+// x^5 of all four state elements, lane l's 12 cells at 12 l: [0, s, s, x2, 0, x2, x2, x4, 0, x4, s, x5]; slots s: l, x2: 4+l, x4: 8+l, x5: 12+l
+constexpr BnSrc bn_map_exp5(int c) {
+    const int l = c / 12, i = c % 12;
+    return (i == 0 || i == 4 || i == 8) ? bK(BK_ZERO) : (i == 1 || i == 2 || i == 10) ? bV(l) : (i == 3 || i == 5 || i == 6) ? bV(4 + l) : (i == 7 || i == 9) ? bV(8 + l) : bV(12 + l);
+}
+// ark: lane l's 5 cells at 5 l: [c][s, c, 1, s + c]; base A = first round constant; slots s: l, s + c: 4 + l
+constexpr BnSrc bn_map_ark(int c) {
+    const int l = c / 5, i = c % 5;
+    return (i == 0 || i == 2) ? bA(l) : i == 1 ? bV(l) : i == 3 ? bK(BK_ONE) : bV(4 + l);
+}
+// mix: lane l's row at 16 l: for j: [acc_j, m[j][l], s_j, acc_{j+1}]; base A = the matrix; slots s_j: j, acc_{j+1} of row l: 4 + 4 l + j
+constexpr BnSrc bn_map_mix(int c) {
+    const int l = c / 16, j = (c % 16) / 4, i = c % 4;
+    return i == 0 ? (j == 0 ? bK(BK_ZERO) : bV(4 + 4 * l + j - 1)) : i == 1 ? bA(4 * j + l) : i == 2 ? bV(j) : bV(4 + 4 * l + j);
+}
+constexpr BnSrc bn_map_consts(int c) { return bA(c); }       // load_constant of M then P (contiguous in the table)
+constexpr BnSrc bn_map_zero(int) { return bK(BK_ZERO); }
+// partial round (hash/poseidon_bn254/permutation.rs:83-110): base A = the round's 7 sparse-matrix entries, base B = its round constant.
+// slots: 0 s0, 1-3 s_k, 4 x2, 5 x4, 6 x5, 7 s0' = x5 + c, 8-11 running sums of the sparse row, 12-14 updated s_k
+constexpr BnSrc bn_map_partial(int c) {
+    if (c < 12) return (c == 0 || c == 4 || c == 8) ? bK(BK_ZERO) : (c == 1 || c == 2 || c == 10) ? bV(0) : (c == 3 || c == 5 || c == 6) ? bV(4) : (c == 7 || c == 9) ? bV(5) : bV(6);
+    if (c < 17) return (c == 12 || c == 14) ? bB(0) : c == 13 ? bV(6) : c == 15 ? bK(BK_ONE) : bV(7);
+    if (c < 37) { const int j = (c - 17) / 5, i = (c - 17) % 5; return (i == 0 || i == 2) ? bA(j) : i == 1 ? (j == 0 ? bK(BK_ZERO) : bV(8 + j - 1)) : i == 3 ? (j == 0 ? bV(7) : bV(j)) : bV(8 + j); }
+    const int k = 1 + (c - 37) / 5, i = (c - 37) % 5;
+    return (i == 0 || i == 2) ? bA(4 + k - 1) : i == 1 ? bV(k) : i == 3 ? bV(7) : bV(12 + k - 1);
+}
 
 template <bool COLS> struct QuadSinkT {
     static constexpr bool kCoop = false;
@@ -267,7 +306,6 @@ template <bool COLS> struct QuadSinkT {
     __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
-    __device__ bool unit_writer() const { return l4 == 0; }
     __device__ int coop_lanes() { return 1; }
     __device__ int coop_lane() { return 0; }
     __device__ uint64_t lane_bcast(uint64_t v, int) { return v; }
@@ -283,233 +321,163 @@ template <bool COLS> struct QuadSinkT {
     __device__ void note_load(uint64_t, int) {}
     __device__ bool coop_load_proof(const ValCfg &) { return false; }
     __device__ void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
-    static __device__ __forceinline__ fr_t shfl4(const fr_t &v, int src) {     // value of lane `src` of this quad
-        fr_t r;
-#pragma unroll
-        for (int i = 0; i < 4; i++) r.l[i] = __shfl(v.l[i], src, 4);
-        return r;
+    // The emitter's working set, by value (a member read behind an opaque call is a FLAT load of the sink object, and flat loads
+    // wait for every cell store in flight).
+    struct Em {
+        sq16_t *val;                   // this quad's value slots (slot s at val + s * BN_SLOT_SQ)
+        const sq16_t *tabh;            // canonical table + (l & 1): the half this lane flushes
+        unsigned long long gdst;       // byte address of this lane's first 16-byte piece of the current layer
+        uint64_t cell0;                // flat index of the layer's first cell
+        int l;
+    };
+    static __device__ __forceinline__ void put(const Em &e, int slot, const fr_t &v) {
+        sq16_t *q = e.val + slot * BN_SLOT_SQ; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]};
     }
-    static __device__ __forceinline__ fr_t shfl4_xor(const fr_t &v, int m) {
-        fr_t r;
-#pragma unroll
-        for (int i = 0; i < 4; i++) r.l[i] = __shfl_xor(v.l[i], m, 4);
-        return r;
+    static __device__ __forceinline__ void put_if(const Em &e, bool on, int slot, const fr_t &v) { if (on) put(e, slot, v); }
+    template <class MapFn> static __device__ __forceinline__ const sq16_t *src_ptr(const Em &e, MapFn map, int c, const sq16_t *baseA, const sq16_t *baseB) {
+        const BnSrc s = map(c);
+        return s.kind == 0 ? e.val + s.idx * BN_SLOT_SQ + (e.l & 1) : s.kind == 1 ? e.tabh + s.idx * 2 : s.kind == 2 ? baseA + s.idx * 2 : baseB + s.idx * 2;
     }
-    // Staged cell store.  A lane that writes a whole 32-byte cell alone issues two 16-byte stores into its own cache line; 64
-    // such lines per store instruction hold the write path to ~3 TB/s device-wide (tools/ubench_store2.hip), while a quad writing
-    // 64 contiguous bytes per instruction streams at the HBM ceiling.  So the owner lanes put their cells into the quad's LDS
-    // region (s_quad_stage, QST cells) and the quad flushes the region, which is contiguous in the advice stream, with all four
-    // lanes writing adjacent 16-byte pieces.  `off` is the cell offset inside the region, negative when this lane has no cell.
-    static __device__ __forceinline__ void stage(int off, const fr_t &v) {
-        if (off >= 0) { sq16_t *q = reinterpret_cast<sq16_t *>(s_quad_stage) + ((threadIdx.x >> 2) * QST + off) * 2; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]}; }
-    }
-    // (static, lane index / cursor by value: a member read after wave_sync's memory clobber is a FLAT load from the sink object, and a
-    // flat load waits for vmcnt(0), i.e. for every cell store still in flight)
-    static __device__ __forceinline__ void flush_run(fr_t *dst_cells, int first, int n, const int l4) {      // staged cells [first, first + n) -> dst_cells[0..n)
-        const sq16_t *src = reinterpret_cast<const sq16_t *>(s_quad_stage) + ((threadIdx.x >> 2) * QST + first) * 2;
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(dst_cells);
-        const int np = 2 * n;                                        // 16-byte pieces; lane k of the quad takes pieces k, k+4, ...
+    // Streams the N cells of a layer: piece p = 4 k + lane is the (p & 1) half of cell p >> 1, so lanes 0, 1 write cell 2 k and lanes
+    // 2, 3 cell 2 k + 1, 64 contiguous bytes per quad.  baseA / baseB: the layer's table bases (already + the lane's half).
+    template <int N, class MapFn> __device__ __forceinline__ void flush_layer(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
+        constexpr int NP = (N + 1) / 2;
+        const bool hiq = e.l >= 2;
+        if constexpr (COLS) {
+            if (cc.hi - e.cell0 < (uint64_t)N || e.cell0 < cc.lo) { flush_layer_cols<N>(e, map, baseA, baseB); return; }
+        }
 #pragma unroll
-        for (int u = 0; u < QST / 2; u += 4) {                       // 4 LDS reads in flight, then their 4 stores
+        for (int k0 = 0; k0 < NP; k0 += 4) {                         // four LDS reads in flight, then their stores
             sq16_t t[4];
 #pragma unroll
-            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) t[v] = src[pc]; }
+            for (int u = 0; u < 4; u++) {
+                const int k = k0 + u;
+                if (k < NP) {
+                    const sq16_t *pa = src_ptr(e, map, 2 * k, baseA, baseB), *pb = (2 * k + 1 < N) ? src_ptr(e, map, 2 * k + 1, baseA, baseB) : pa;
+                    t[u] = *(hiq ? pb : pa);
+                }
+            }
 #pragma unroll
-#ifdef H2W_ABL_NOFLUSH      // timing-only ablation: the staged cells are read back but not written to memory
-            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np && t[v].x == 0x123456789abcull) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
-#else
-            for (int v = 0; v < 4; v++) { const int pc = (u + v) * 4 + l4; if (pc < np) { H2W_GSTORE64(dst + 2 * pc, t[v].x); H2W_GSTORE64(dst + 2 * pc + 1, t[v].y); } }
-#endif
-            if ((u + 4) * 4 >= np) break;
+            for (int u = 0; u < 4; u++) {
+                const int k = k0 + u;
+                if (k < NP) {
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(e.gdst + (unsigned long long)k * 64);
+                    if (2 * k + 1 < N || !hiq) { H2W_GSTORE64(g, t[u].x); H2W_GSTORE64(g + 1, t[u].y); }
+                }
+            }
+        }
+        e.cell0 += (uint64_t)N; e.gdst += (unsigned long long)N * 32;
+    }
+    // column-major layout, a layer that crosses into the next column (rare): per-cell addresses
+    template <int N, class MapFn> __device__ __noinline__ void flush_layer_cols(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
+        if constexpr (COLS) {
+            const bool hiq = e.l >= 2;
+            for (int k = 0; k < (N + 1) / 2; k++) {
+                const int c = 2 * k + (hiq ? 1 : 0);
+                if (c < N) {
+                    // (the map is a compile-time function: evaluate it through a small switch-free loop over both candidates)
+                    const sq16_t *pa = src_ptr_rt(e, map, 2 * k, baseA, baseB), *pb = (2 * k + 1 < N) ? src_ptr_rt(e, map, 2 * k + 1, baseA, baseB) : pa;
+                    const sq16_t t = *(hiq ? pb : pa);
+                    const uint64_t a = cc.map(e.cell0 + (uint64_t)c);
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned long long>(out + a) + (unsigned long long)(e.l & 1) * 16);
+                    H2W_GSTORE64(g, t.x); H2W_GSTORE64(g + 1, t.y);
+                }
+            }
+            e.cell0 += (uint64_t)N;
+            e.gdst = reinterpret_cast<unsigned long long>(out + cc.map(e.cell0)) + (unsigned long long)e.l * 16;
         }
     }
-    // column-major layout: a region can straddle one column boundary (out of line: only this mode pays for it)
-    static __device__ __noinline__ void flush_cols(fr_t *out, ColPolicy<true> &cc, uint64_t cell0, int n, const int l4) {
-        const uint64_t a0 = cc.map(cell0);
-        const int n0 = (cc.hi - cell0 < (uint64_t)n) ? (int)(cc.hi - cell0) : n;
-        flush_run(out + a0, 0, n0, l4);
-        if (n0 < n) { const uint64_t a1 = cc.map(cell0 + (uint64_t)n0); flush_run(out + a1, n0, n - n0, l4); }
+    template <class MapFn> static __device__ __forceinline__ const sq16_t *src_ptr_rt(const Em &e, MapFn map, int c, const sq16_t *baseA, const sq16_t *baseB) {
+        const BnSrc s = map(c);
+        return s.kind == 0 ? e.val + s.idx * BN_SLOT_SQ + (e.l & 1) : s.kind == 1 ? e.tabh + s.idx * 2 : s.kind == 2 ? baseA + s.idx * 2 : baseB + s.idx * 2;
     }
-    // flush the n staged cells to the advice cells [cell0, cell0 + n)
-    static __device__ __forceinline__ void flush(fr_t *out, ColPolicy<COLS> &cc, uint64_t &cell0, int &n, const int l4) {
-        wave_sync();
-        if constexpr (!COLS) flush_run(out + cell0, 0, n, l4);
-        else flush_cols(out, cc, cell0, n, l4);
-        wave_sync();
-        cell0 += (uint64_t)n; n = 0;
-    }
-    // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself (hash/poseidon_bn254/permutation.rs:48-203):
-    // lane i owns state element i and the cells of "its" ops (x^5 of element i, ark i, row i of the mix, term j of the
-    // sparse row, column update k), each a contiguous run of 5-16 cells.  Hybrid arithmetic: canonical state, constants
-    // pre-multiplied by R for const*var products, x^5 in 5 Montgomery products.  No second pass over the permutations.
+    // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself.
     __device__ __noinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
         bool zc = zc_ref;                      // by value: a reference would be re-read with a flat load (vmcnt(0)) at every mix
         const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
-        uint64_t base = cell_off;             // flat cell index of the staging region's first cell
-        fr_t *const outp = out;      // (by value: see flush)
-        int so = 0;                           // cells staged (quad-uniform)
+        Em e; e.l = l;
+        e.val = s_bn_val + ((threadIdx.x >> 6) * BN_NSLOT * BN_SLOT_SQ) + ((threadIdx.x & 63) >> 2) * 2;
+        e.tabh = s_bn_tab + (l & 1);
+        e.cell0 = cell_off;
+        e.gdst = reinterpret_cast<unsigned long long>(out + cc.map(cell_off)) + (unsigned long long)l * 16;
         fr_t s = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
-#ifdef H2W_ABL_NOSTORE
-        auto W = [&](int off, const fr_t &v) { if (cfg.P.ninv == 12345) stage(off < 0 ? -1 : so + off, v); };
-#else
-        auto W = [&](int off, const fr_t &v) { stage(off < 0 ? -1 : so + off, v); };
-#endif
-        auto W64 = [&](int off, uint64_t v) { W(off, fr_from_u64(v)); };
-        auto need = [&](int n) { if (so + n > QST) flush(outp, cc, base, so, l); };
-        // x^5: 12 cells at region offset p (p < 0: this lane has no S-box here and keeps its s)
-        auto exp5_all = [&]() {                          // S-box on every lane: 4 x 12 cells, lane l's at 12 l
+        auto exp5_all = [&]() {                          // S-box on every lane
             const fr_t X = fr_mont_mul(s, r2, ninv);
             const fr_t x2 = fr_mont_mul(s, X, ninv), X2 = fr_mont_mul(X, X, ninv);
             const fr_t x4 = fr_mont_mul(x2, X2, ninv), x5 = fr_mont_mul(x4, X, ninv);
-#pragma unroll
-            for (int h = 0; h < QHALVES; h++) {
-                need(48 / QHALVES);
-                const int q = QHALVES == 1 ? 12 * l : ((l >> 1) == h ? 12 * (l & 1) : -64);      // q + i stays negative for a lane without cells in this pass
-                W64(q, 0); W(q + 1, s); W(q + 2, s); W(q + 3, x2);
-                W64(q + 4, 0); W(q + 5, x2); W(q + 6, x2); W(q + 7, x4);
-                W64(q + 8, 0); W(q + 9, x4); W(q + 10, s); W(q + 11, x5);
-                so += 48 / QHALVES;
-            }
+            put(e, l, s); put(e, 4 + l, x2); put(e, 8 + l, x4); put(e, 12 + l, x5);
+            flush_layer<48>(e, bn_map_exp5, e.tabh, e.tabh);
             s = x5;
         };
-        auto add_const = [&](int p, const fr_t &c) {                  // [c][s, c, 1, s+c]
-            const int q = p < 0 ? -64 : p; const fr_t ns = fr_add(s, c);
-            W(q, c); W(q + 1, s); W(q + 2, c); W64(q + 3, 1); W(q + 4, ns);
-            if (p >= 0) s = ns;
+        auto ark = [&](int it) {
+            const fr_t ns = fr_add(s, bnk(0, BK_C + it + l));
+            put(e, l, s); put(e, 4 + l, ns);
+            flush_layer<20>(e, bn_map_ark, e.tabh + (BK_C + it) * 2, e.tabh);
+            s = ns;
         };
-        // (constants are requested before a possible flush, see the partial rounds)
-        auto ark = [&](int it) { const fr_t kc = bnk(0, BK_C + it + l); need(20); add_const(5 * l, kc); so += 20; };
         auto mix = [&](int which) {                      // which 0: M, 1: P
-            if (!zc) { need(1); W64(l == 0 ? 0 : -64, 0); so += 1; zc = true; }
-            if constexpr (QHALVES == 1) {
-                need(64);
-                fr_t acc = fr_zero(); const int p = 16 * l;
-                for (int j = 0; j < 4; j++) {
-                    const fr_t sj = shfl4(s, j);
-                    const fr_t nacc = fr_add(fr_mont_mul(sj, bnk(1, (which ? BK_P : BK_M) + 4 * j + l), ninv), acc);
-                    W(p + 4 * j, acc); W(p + 4 * j + 1, bnk(0, (which ? BK_P : BK_M) + 4 * j + l)); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, nacc); acc = nacc;
-                }
-                s = acc; so += 64;
-            } else {
-                // the canonical constants are requested before the first flush (loads and stores share vmcnt in order); the row's
-                // partial sums stay in registers across the two staging passes
-                fr_t kc[4], acc[5];
-#pragma unroll
-                for (int j = 0; j < 4; j++) kc[j] = bnk(0, (which ? BK_P : BK_M) + 4 * j + l);
-                acc[0] = fr_zero();
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[j + 1] = fr_add(fr_mont_mul(shfl4(s, j), bnk(1, (which ? BK_P : BK_M) + 4 * j + l), ninv), acc[j]);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    need(32);
-                    const int p = (l >> 1) == h ? 16 * (l & 1) : -64;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { const fr_t sj = shfl4(s, j); W(p + 4 * j, acc[j]); W(p + 4 * j + 1, kc[j]); W(p + 4 * j + 2, sj); W(p + 4 * j + 3, acc[j + 1]); }
-                    so += 32;
-                }
-                s = acc[4];
+            if (!zc) { flush_layer<1>(e, bn_map_zero, e.tabh, e.tabh); zc = true; }     // the Context's first load_zero (halo2-base caches it afterwards)
+            const int mb = which ? BK_P : BK_M;
+            put(e, l, s);
+            fr_t acc = fr_zero();
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                const sq16_t a0 = e.val[j * BN_SLOT_SQ], a1 = e.val[j * BN_SLOT_SQ + 1];       // s_j, staged above (an LDS read: j is a loop index)
+                fr_t sj; sj.l[0] = a0.x; sj.l[1] = a0.y; sj.l[2] = a1.x; sj.l[3] = a1.y;
+                acc = fr_add(fr_mont_mul(sj, bnk(1, mb + 4 * j + l), ninv), acc);
+                put(e, 4 + 4 * l + j, acc);
             }
-        };
-        auto consts32 = [&]() {                          // load_constant of M then P (full_rounds prologue)
-            need(32);
-            for (int u = 0; u < 8; u++) { const int t = 8 * l + u; W(t, bnk(0, BK_M + t)); }
-            so += 32;
+            flush_layer<64>(e, bn_map_mix, e.tabh + mb * 2, e.tabh);
+            s = acc;
         };
         ark(0);
+#pragma unroll 1
         for (int half = 0; half < 2; half++) {
             if (half == 1) {
+#pragma unroll 1
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-                    // This round's constants are fetched BEFORE the flush of the previous round's cells: loads and stores share vmcnt
-                    // in order, so a constant requested after the flush's stores would wait for all of them to reach memory.
-                    const int ix = (BN_WIDTH * 2 - 1) * r + l, lm = l > 0 ? l - 1 : 0, iy = (BN_WIDTH * 2 - 1) * r + BN_WIDTH + lm;
-                    const fr_t kc = bnk(0, BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r);
-                    const fr_t ksx = bnk(0, BK_S + ix), ksxm = bnk(1, BK_S + ix), ksy = bnk(0, BK_S + iy), ksym = bnk(1, BK_S + iy);
-                    need(QST >= 64 ? 52 : 17);             // (QST 32: the round's three cell groups - 17, 20, 15 - are placed one by one)
-                    // Five wavefront-level Montgomery products per partial round instead of seven: the lanes that have no S-box do
-                    // their own work inside the S-box's instruction stream.
+                    // Five wavefront-level Montgomery products per partial round: the lanes that have no S-box do their own work
+                    // inside the S-box's instruction stream.
                     //   A: lane 0  X = s0 R          | lanes 1-3  S_j * s_j          (their terms of the sparse row; s_j is not touched by the S-box)
                     //   B: lane 0  x2 = s0 X         | lane 1     X2 = X X
                     //   C: lane 0  x4 = x2 X2 ;  D: lane 0  x5 = x4 X ;  then s0' = x5 + c
                     //   E: lane 0  S_0 * s0'         | lanes 1-3  S'_k * s0'         (column update)
+                    const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, lm = l > 0 ? l - 1 : 0, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                    const fr_t ksxm = bnk(1, ix + l);
                     const fr_t A_ = fr_mont_mul(s, l == 0 ? r2 : ksxm, ninv);
-                    const fr_t Xb = shfl4(A_, 0);
+                    const fr_t Xb = quad_bcast<0>(A_);
                     const fr_t B_ = fr_mont_mul(l == 0 ? s : Xb, Xb, ninv);
-                    const fr_t X2b = shfl4(B_, 1);
+                    const fr_t X2b = quad_bcast<1>(B_);
                     const fr_t x4 = fr_mont_mul(B_, X2b, ninv), x5 = fr_mont_mul(x4, Xb, ninv);
-                    {   // lane 0's S-box cells [0,s,s,x2, 0,x2,x2,x4, 0,x4,s,x5] and +c [c][x5, c, 1, x5+c]
-                        const int q = l == 0 ? 0 : -64; const fr_t ns = fr_add(x5, kc);
-                        W64(q, 0); W(q + 1, s); W(q + 2, s); W(q + 3, B_);
-                        W64(q + 4, 0); W(q + 5, B_); W(q + 6, B_); W(q + 7, x4);
-                        W64(q + 8, 0); W(q + 9, x4); W(q + 10, s); W(q + 11, x5);
-                        W(q + 12, kc); W(q + 13, x5); W(q + 14, kc); W64(q + 15, 1); W(q + 16, ns);
-                        if (l == 0) s = ns;
-                    }
-                    so += 17;
-                    if constexpr (QST < 64) need(20);
-                    const fr_t s0 = shfl4(s, 0);
-                    const fr_t E_ = fr_mont_mul(s0, l == 0 ? ksxm : ksym, ninv);
-                    const fr_t pr = l == 0 ? E_ : A_;                                    // S[j] * s_j
-                    fr_t incl = pr, t = shfl4_up(incl, 1); if (l >= 1) incl = fr_add(incl, t);
-                    t = shfl4_up(incl, 2); if (l >= 2) incl = fr_add(incl, t);
-                    fr_t excl = shfl4_up(incl, 1); if (l == 0) excl = fr_zero();
-                    { const int p = 5 * l; W(p, ksx); W(p + 1, excl); W(p + 2, ksx); W(p + 3, s); W(p + 4, incl); }
-                    so += 20;
-                    if constexpr (QST < 64) need(15);
-                    const fr_t ns0 = shfl4(incl, 3);
-                    {
-                        const int p = l > 0 ? 5 * lm : -64;
-                        const fr_t nv = fr_add(E_, s);
-                        W(p, ksy); W(p + 1, s); W(p + 2, ksy); W(p + 3, s0); W(p + 4, nv);
-                        s = l > 0 ? nv : ns0;
-                    }
-                    so += 15;
+                    const fr_t s0n = fr_add(x5, bnk(0, ic));
+                    put(e, l, s);                                        // slots 0-3: the state before the round
+                    put_if(e, l == 0, 4, B_); put_if(e, l == 0, 5, x4); put_if(e, l == 0, 6, x5); put_if(e, l == 0, 7, s0n);
+                    const fr_t s0 = quad_bcast<0>(s0n);
+                    const fr_t E_ = fr_mont_mul(s0, l == 0 ? ksxm : bnk(1, ix + BN_WIDTH + lm), ninv);
+                    fr_t incl = l == 0 ? E_ : A_;                        // S[j] * s_j, then the running sums over the quad
+                    { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
+                    { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
+                    put(e, 8 + l, incl);
+                    const fr_t nv = fr_add(E_, s);
+                    put_if(e, l > 0, 12 + lm, nv);
+                    const fr_t ns0 = quad_bcast<3>(incl);
+                    s = l > 0 ? nv : ns0;
+                    flush_layer<52>(e, bn_map_partial, e.tabh + ix * 2, e.tabh + ic * 2);
                 }
             }
-            consts32();
-            for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) {
+            // full_rounds(is_first = half == 0) (:112-160): load_constant of M and P, then 4 x (x^5, [ark], mix)
+            flush_layer<32>(e, bn_map_consts, e.tabh + BK_M * 2, e.tabh);
+#pragma unroll 1
+            for (int r = 0; r < BN_FULL_ROUNDS / 2; r++) {
+                const bool last = r == BN_FULL_ROUNDS / 2 - 1;
                 exp5_all();
-                ark(half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
-                mix(0);
+                if (!(half == 1 && last)) ark(half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
+                mix(half == 0 && last ? 1 : 0);
             }
-            exp5_all();
-            if (half == 0) { ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(1); } else mix(0);
         }
-        flush(outp, cc, base, so, l);
-        for (int j = 0; j < 4; j++) st[j] = shfl4(s, j);
-        cell_off = base; zc_ref = zc;
+        st[0] = quad_bcast<0>(s); st[1] = quad_bcast<1>(s); st[2] = quad_bcast<2>(s); st[3] = quad_bcast<3>(s);
+        cell_off = e.cell0; zc_ref = zc;
         return true;
-    }
-    static __device__ __forceinline__ fr_t shfl4_up(const fr_t &v, int d) {
-        fr_t r;
-#pragma unroll
-        for (int i = 0; i < 4; i++) r.l[i] = __shfl_up(v.l[i], d, 4);
-        return r;
-    }
-    __device__ __noinline__ void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) {
-        const int l = l4; const uint64_t ninv = P.ninv;
-        fr_t mine = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
-        fr_t s = fr_mont_mul(mine, P.r2, ninv);
-        auto exp5 = [&](const fr_t &x) { fr_t x2 = fr_mont_mul(x, x, ninv), x4 = fr_mont_mul(x2, x2, ninv); return fr_mont_mul(x4, x, ninv); };
-        auto mix = [&](const h2w_fr_t (*m)[4]) {
-            fr_t acc = fr_zero();
-            for (int j = 0; j < 4; j++) { const fr_t sj = shfl4(s, j); acc = fr_add(acc, fr_mont_mul(m[j][l], sj, ninv)); }
-            s = acc;
-        };
-        s = fr_add(s, km->bn_c[l]);
-        for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { s = exp5(s); s = fr_add(s, km->bn_c[(r + 1) * BN_WIDTH + l]); mix(km->bn_m); }
-        s = exp5(s); s = fr_add(s, km->bn_c[(BN_FULL_ROUNDS / 2) * BN_WIDTH + l]); mix(km->bn_p);
-        for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-            if (l == 0) s = fr_add(exp5(s), km->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]);
-            const fr_t s0 = shfl4(s, 0);
-            fr_t p = fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + l], s, ninv);            // S[j] * s_j
-            if (l > 0) s = fr_add(s, fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + BN_WIDTH + l - 1], s0, ninv));
-            p = fr_add(p, shfl4_xor(p, 1)); p = fr_add(p, shfl4_xor(p, 2));                     // sum over the quad
-            if (l == 0) s = p;
-        }
-        for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { s = exp5(s); s = fr_add(s, km->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH + l]); mix(km->bn_m); }
-        s = exp5(s); mix(km->bn_m);
-        const fr_t o = fr_mont_mul(s, fr_from_u64(1), ninv);
-        for (int j = 0; j < 4; j++) st[j] = shfl4(o, j);
     }
 };
 typedef QuadSinkT<false> QuadSink;

@@ -37,10 +37,7 @@ struct ValCfg {
     const fr_t *inv_pos, *inv_neg;   // inverses of +-k, k < INV_TAB (Assigned::Rational(1,x) cells of is_zero)
     const StrandTable *st;           // null on the sequential (plan) run
     bool split;                      // true: merkle calls are skipped (their cells belong to merkle strands)
-    bool split_bn;                   // true: BN254 permutations are recorded as units (input state) and evaluated natively
-    fr_t *units;                     // this proof's unit inputs [n_units][4] (split_bn)
-    const h2w_poseidon_consts_t *consts_mont;   // constants in Montgomery form (split_bn)
-    uint64_t bn_perm_cells;          // cells of one permute call (4032)
+    bool split_bn;                   // true: the sink emits a PoseidonBN254 permutation's cells itself (QuadSink::bn_emit_inline)
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
 };
 
@@ -192,13 +189,7 @@ template <class Sink> struct ValBackend {
     }
     // ---------------------------------------------------------------- BN254 permutation units
     HF bool bn_perm_unit(Fr *st, const h2w_poseidon_consts_t *) {
-        if (!cfg.split_bn) return false;
-        if (sink.bn_emit_inline(st, cfg, zero_cached)) return true;      // the strand's own lanes emit the permutation's cells (QuadSink)
-        fr_t *u = cfg.units + 4 * unit_idx; unit_idx++;
-        if (sink.unit_writer()) for (int i = 0; i < 4; i++) g_store_fr(u + i, st[i]);
-        sink.bn_native(st, cfg.consts_mont, cfg.P);
-        sink.skip(0, cfg.bn_perm_cells + (zero_cached ? 0 : 1)); zero_cached = true;
-        return true;
+        return cfg.split_bn && sink.bn_emit_inline(st, cfg, zero_cached);      // the strand's own lanes emit the permutation's cells (QuadSink)
     }
     HF void bn_perm_begin() { sink.bn_perm_begin(zero_cached); }
     HF void bn_perm_end() { sink.bn_perm_end(zero_cached); unit_idx++; }
@@ -247,8 +238,6 @@ template <bool COLS> struct DevSinkT {
     HF void bn_perm_end(bool) {}
     HF void note_load(uint64_t, int) {}
     HF bool coop_load_proof(const ValCfg &) { return false; }
-    HF void bn_native(fr_t *st, const h2w_poseidon_consts_t *km, const FrParams &P) { bn_poseidon_native(st, km, P); }
-    HF bool unit_writer() const { return true; }
     HF bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     HF int coop_lanes() { return 1; }
     HF int coop_lane() { return 0; }

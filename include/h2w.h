@@ -248,9 +248,14 @@ int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest
 /* Output format: the stream is canonical little-endian Fr (what Fr::from_repr / to_repr use).  For a consumer that copies cells into
  * halo2curves' in-memory representation (Montgomery form, R = 2^256) this converts n_cells cells in place on the device. */
 int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
-/* Kernel timing of a batch call, in ms, from HIP events the library records on the call's stream:
- * ms[0] = prologue strands, ms[1] = query + Merkle strands, ms[2] = BN254 permutation-unit emission,
- * ms[3] = expansion kernel, ms[4] = whole batch.
+/* Scheduling options of a plan.  H2W_OPT_FORK_CHAINS (default 1): with PoseidonBN254 Merkle caps the chain kernel of a batch call
+ * runs on a library-owned side stream beside the query-glue and expansion kernels of the same call (they depend on the prologue
+ * only); the caller's stream still completes when the whole advice is written.  0: every kernel on the caller's stream. */
+#define H2W_OPT_FORK_CHAINS 1
+int h2w_plan_configure(h2w_plan *, int option, int value);
+/* Kernel timing of a batch call, in ms, from HIP events the library records on the streams it launches on:
+ * ms[0] = prologue strands, ms[1] = query glue strands (+ Goldilocks-Poseidon Merkle strands), ms[2] = PoseidonBN254 Merkle
+ * chain kernel (0 with Goldilocks-Poseidon caps), ms[3] = expansion kernel, ms[4] = whole call.
  * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
 int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
 int h2w_plan_last_timing(h2w_plan *, float ms[5]);
