@@ -212,6 +212,7 @@ class Plan:
         self.proof_words = int(self.L.h2w_plan_proof_words(self.p))
         self.num_records = int(self.L.h2w_plan_num_records(self.p))
         self.num_record_cells = int(self.L.h2w_plan_num_record_cells(self.p))
+        self.num_chain_cells = int(self.L.h2w_plan_num_chain_cells(self.p))
 
     def close(self):
         if getattr(self, "p", None):
@@ -232,6 +233,12 @@ class Plan:
             _ck(self.L.h2w_fri_witness_batch(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream), "h2w_fri_witness_batch")
         else:
             _ck(self.L.h2w_fri_witness_batch2(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, emit_stream), "h2w_fri_witness_batch2")
+
+    def strand_layout(self):
+        """(prologue cells, cells of query block 0, cells of a later query block, cells per proof) — h2w_plan_strand_layout."""
+        out = (C.c_uint64 * 4)()
+        _ck(self.L.h2w_plan_strand_layout(self.p, out), "h2w_plan_strand_layout")
+        return tuple(int(x) for x in out)
 
     def configure(self, option, value):
         _ck(self.L.h2w_plan_configure(self.p, option, value), "h2w_plan_configure")

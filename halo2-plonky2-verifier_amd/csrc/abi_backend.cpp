@@ -15,7 +15,7 @@ namespace h2w {
 
 struct AbiBackend {
     typedef h2w_assigned_t Gl; typedef h2w_assigned_t Bool; typedef h2w_assigned_t Fr; typedef h2w_assigned_t Big;
-    static constexpr bool kCoopPoseidon = false;
+    static constexpr bool kCoopPoseidon = false, kSplitOnly = false;
     h2w_ctx *ctx; int mode; const uint64_t *proof; std::vector<h2w_assigned_t> wires; uint32_t status = 0; int rc = 0;
     AbiBackend(h2w_ctx *c, int hash_mode, const uint64_t *proof_words, size_t n_words) : ctx(c), mode(hash_mode), proof(proof_words), wires(n_words) {}
     void ck(int r) { if (r != 0 && rc == 0) rc = r; }

@@ -17,14 +17,13 @@
 #include "common.h"
 #include "valbackend.h"
 #include "coop.h"
+#include "batchargs.h"
 
 namespace h2w {
 
-typedef ValBackend<DevSink> DevB;
-typedef ChallengeBlock<DevB> DevCB;   // (the wire types of every backend coincide: one ChallengeBlock layout)
 
 struct PlanSink {
-    static constexpr bool kCoop = false;
+    static constexpr bool kCoop = false, kSplitOnly = false;
     void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     std::vector<uint64_t> *meta; const TemplateTable *tt; StrandTable *st;
     uint64_t nrec = 0, cell_off = 0, cur_q_rec = 0, cur_q_cell = 0, mk_rec0 = 0, mk_cell0 = 0; bool mk_zc = false;
@@ -66,30 +65,6 @@ struct PlanSink {
     void query_end(int q, uint64_t) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; st->q_nunit[q] = nunit - cur_q_unit; } }
 };
 
-struct BatchArgs {
-    h2w_shape_t shape; const h2w_poseidon_consts_t *consts;
-    const uint64_t *proofs; uint64_t proof_words;
-    rec_t *recs; uint64_t rec_stride;
-    fr_t *out; uint64_t cell_stride;
-    DevCB *cbs; uint32_t *status;
-    const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
-    StrandTable st; FrParams P;
-    int nproofs, role_base, dbg_skip_perm;
-    const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
-    const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
-    ColMap cm;      // column-major emission (starts == nullptr: flat advice)
-    int shard_rank, shard_world;      // (proof, query) units are dealt round-robin to shard_world ranks (1: everything)
-};
-__device__ __forceinline__ bool own_unit(const BatchArgs &A, int p, int q) { return A.shard_world <= 1 || (int)(((long long)p * A.shape.num_queries + q) % A.shard_world) == A.shard_rank; }
-
-__device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
-    ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
-    c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = &A.st; c.split = true;
-    c.load_items = A.load_items; c.n_load_items = A.n_load_items; c.load_nrec = A.load_nrec; c.load_ncell = A.load_ncell;
-    c.split_bn = false;
-    return c;
-}
-
 // Register budget of the strand kernels (the attribute propagates to their callees): H2W_QUAD_WAVES wavefronts per SIMD.
 #define H2W_WAVES __attribute__((amdgpu_waves_per_eu(1, 1)))
 // the PoseidonBN254 chain kernel: two blocks of QUAD_BLOCK threads per CU by LDS (32.9 KB of tables + 10 KB of value slots per wavefront)
@@ -112,6 +87,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_coop(Batch
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
     CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm; sink.cc.init(A.cm);
+    sink.emit = own_prologue(A, p);      // every rank of a sharded run needs the challenges; the proof's owner emits the prologue block
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
@@ -171,24 +147,6 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void
     if ((threadIdx.x & 3) == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
-// query glue strands (FriChip::verify_query_round minus its Merkle proofs, fri/mod.rs:338-444): one lane per (proof, query)
-template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_strands(BatchArgs A) {
-    typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
-    __builtin_amdgcn_s_setprio(3);
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nq = A.shape.num_queries;
-    if (idx >= A.nproofs * nq) return;
-    const int p = idx / nq, q = idx % nq;
-    if (!own_unit(A, p, q)) return;
-    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
-    sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
-    const ChallengeBlock<DevB> &cb = *reinterpret_cast<const ChallengeBlock<DevB> *>(&A.cbs[p]);
-    DevB be(sink, make_cfg(A, p), true);
-    Verifier<DevB> V(be, A.shape, A.consts);
-    V.query_round(q, cb);
-    if (be.status) atomicCAS(&A.status[p], 0u, be.status);
-}
-
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -231,7 +189,9 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     const h2w_shape_t &s = *shape;
     if (s.lookup_bits < 2 || s.lookup_bits > 28 || s.num_queries < 1 || s.num_queries > MAX_QUERIES || s.cap_height < 0 || (1 << s.cap_height) > MAX_CAP ||
         s.arity_bits < 1 || (1 << s.arity_bits) > MAX_ARITY || s.n_cols + s.n_perm_z + s.n_quotient > MAX_BATCH_POLYS || s.hash_mode < 0 || s.hash_mode > 1 ||
-        s.degree_bits + s.rate_bits > 63 || s.degree_bits + s.rate_bits < s.cap_height || s.pow_bits < 0 || s.pow_bits > 63) {
+        s.degree_bits + s.rate_bits > 63 || s.degree_bits + s.rate_bits < s.cap_height || s.pow_bits < 0 || s.pow_bits > 63 ||
+        s.degree_bits < 0 || s.rate_bits < 0 || s.n_cols < 1 || s.n_perm_z < 0 || s.n_quotient < 1 || s.n_pis < 0 || s.num_challenges < 0 || s.final_poly_bits < 0 ||
+        (s.n_perm_z > 0 && s.perm_batch_size < 1)) {
         set_error("h2w_plan_compile: unsupported shape"); return nullptr;
     }
     h2w_plan *pl = new h2w_plan(s.lookup_bits);
@@ -278,8 +238,8 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         pl->device = -1; return pl;
     }
     if (device_id < 0 || device_id >= ndev) { set_error("h2w_plan_compile: device_id out of range"); delete pl; return nullptr; }
+    DeviceGuard dg(device_id);
     auto up = [&]() -> int {
-        H2W_HIP(hipSetDevice(device_id));
         if (pl->dt.upload(pl->tt) != 0) return -1;
         H2W_HIP(hipMalloc((void **)&pl->d_meta, meta.size() * sizeof(uint64_t)));
         H2W_HIP(hipMemcpy(pl->d_meta, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -303,11 +263,12 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         pl->ev_ready = true;
         return 0;
     };
-    if (up() != 0) { delete pl; return nullptr; }
+    if (up() != 0) { h2w_plan_free(pl); return nullptr; }      // (frees whatever the partial upload allocated)
     return pl;
 }
 void h2w_plan_free(h2w_plan *p) {
     if (!p) return;
+    DeviceGuard dg(p->device);
     if (p->d_meta) (void)hipFree(p->d_meta);
     if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
@@ -326,6 +287,17 @@ uint64_t h2w_plan_num_cells(const h2w_plan *p) { return p ? p->ncells : 0; }
 uint64_t h2w_plan_proof_words(const h2w_plan *p) { return p ? p->pl.total : 0; }
 uint64_t h2w_plan_num_records(const h2w_plan *p) { return p ? p->nrec : 0; }
 uint64_t h2w_plan_num_record_cells(const h2w_plan *p) { return p ? p->rec_cells : 0; }
+int h2w_plan_strand_layout(const h2w_plan *p, uint64_t out[4]) {
+    if (!p || !out) { set_error("h2w_plan_strand_layout: null argument"); return -1; }
+    out[0] = p->st.pro_ncell; out[1] = p->st.q_ncell[0]; out[2] = p->shape.num_queries > 1 ? p->st.q_ncell[1] : p->st.q_ncell[0]; out[3] = p->ncells;
+    return 0;
+}
+uint64_t h2w_plan_num_chain_cells(const h2w_plan *p) {      // cells of the Merkle strands: what k_merkle_bn_quad writes per proof (hash_mode 1)
+    if (!p) return 0;
+    uint64_t n = 0;
+    for (int k = 0; k < MK_KINDS; k++) n += p->st.mk_ncell[0][k] + (uint64_t)(p->shape.num_queries - 1) * p->st.mk_ncell[1][k];
+    return n;
+}
 static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_cbs, size_t &o_status, size_t &o_units, size_t &total) {
     size_t o = 0;
     o_recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
@@ -367,6 +339,7 @@ int h2w_fri_witness_batch_columns(h2w_plan *p, const uint64_t *proofs_dev, uint6
         if (start + len > p->ncells || len > ((uint64_t)1 << k) || len < 2) { set_error("h2w_fri_witness_batch_columns: break points do not fit the stream"); return -1; }
         h[c] = start; h[ncols + c] = len; start += len - (c < n_bp ? 1 : 0);
     }
+    DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
     if (h != p->h_col_tab || k != p->col_k) {      // (re)upload the column table; plans are single-threaded handles (include/h2w.h)
         H2W_HIP(hipDeviceSynchronize());             // a previous call on another stream may still read the old table
@@ -397,6 +370,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
     if (n_proofs * (uint64_t)p->shape.num_queries > 0x7fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
+    DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_, estream = (hipStream_t)emit_stream_;
     size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
     char *ws = (char *)workspace_dev;
@@ -443,7 +417,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     // 3. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per (proof, query);
     //    Goldilocks-Poseidon Merkle strands (hash_mode 0): one cooperating wavefront per (proof, query, tree) - these do write records
     if (!(dbg_skip & 2)) {
-        if (cm.starts) hipLaunchKernelGGL(k_strands<true>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+        launch_glue_strands(A, nlanes, stream);
         if (p->shape.hash_mode == 0) {
             if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_coop<true>, dim3(nlanes, nkinds), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_merkle_gl_coop<false>, dim3(nlanes, nkinds), dim3(64), 0, stream, A);
         }
@@ -476,6 +450,7 @@ int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, voi
     if (!p || p->device < 0) { set_error("h2w_fri_expand_records: no HIP device"); return -1; }
     if (!advice_dev || !workspace_dev) { set_error("h2w_fri_expand_records: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
+    DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
     size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
     char *ws = (char *)workspace_dev;
@@ -568,6 +543,7 @@ int h2w_layout_columns(const void *advice_dev, uint64_t n_cells, uint64_t proof_
         h[c] = start; h[ncols + c] = len; start += len - (c < n_bp ? 1 : 0);
     }
     if (ncols > 65535 || n_proofs > 65535) { set_error("h2w_layout_columns: too many columns / proofs per call"); return -1; }
+    DeviceGuard dg(device_of(advice_dev));
     hipStream_t stream = (hipStream_t)stream_; uint64_t *d = nullptr;
     H2W_HIP(hipMallocAsync((void **)&d, h.size() * sizeof(uint64_t), stream));
     H2W_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -597,6 +573,7 @@ int h2w_layout_lookup_columns(h2w_plan *p, const void *advice_dev, uint64_t proo
     if (!out_dev) return 0;                    // size query
     if (!advice_dev) { set_error("h2w_layout_lookup_columns: null advice"); return -1; }
     if (p->device < 0) { set_error("h2w_layout_lookup_columns: no HIP device"); return -1; }
+    DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
     if (ensure_lookup_cells(p) != 0) return -1;
     if (n_proofs == 0 || ncols == 0) return 0;
@@ -640,6 +617,7 @@ static int ensure_lookup_cells(h2w_plan *p) {
 int h2w_check_constraints(h2w_plan *p, const void *advice_dev, uint64_t proof_stride_cells, uint64_t n_proofs, uint64_t bad_out[2], void *stream_) {
     if (!p || !advice_dev || !bad_out) { set_error("h2w_check_constraints: null argument"); return -1; }
     if (p->device < 0) { set_error("h2w_check_constraints: no HIP device"); return -1; }
+    DeviceGuard dg(p->device);
     if (h2w_plan_metadata(p) != 0 || ensure_lookup_cells(p) != 0) return -1;
     bad_out[0] = bad_out[1] = 0;
     if (n_proofs == 0) return 0;
@@ -651,13 +629,18 @@ int h2w_check_constraints(h2w_plan *p, const void *advice_dev, uint64_t proof_st
     }
     unsigned long long *d_bad = nullptr;
     H2W_HIP(hipMallocAsync((void **)&d_bad, 16, stream));
-    H2W_HIP(hipMemsetAsync(d_bad, 0, 16, stream));
-    hipLaunchKernelGGL(k_check_gates, dim3(2048, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, p->ncells, p->d_sel_bits, p->P, d_bad);
-    if (p->n_lookups) hipLaunchKernelGGL(k_check_lookups, dim3(1024, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, p->d_lookup_cells, p->n_lookups, (int)p->shape.lookup_bits, d_bad);
     unsigned long long h[2] = {0, 0};
-    H2W_HIP(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, stream));
-    H2W_HIP(hipStreamSynchronize(stream));
-    H2W_HIP(hipFreeAsync(d_bad, stream));
+    auto run = [&]() -> int {
+        H2W_HIP(hipMemsetAsync(d_bad, 0, 16, stream));
+        hipLaunchKernelGGL(k_check_gates, dim3(2048, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, p->ncells, p->d_sel_bits, p->P, d_bad);
+        if (p->n_lookups) hipLaunchKernelGGL(k_check_lookups, dim3(1024, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, p->d_lookup_cells, p->n_lookups, (int)p->shape.lookup_bits, d_bad);
+        H2W_HIP(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, stream));
+        H2W_HIP(hipStreamSynchronize(stream));
+        return 0;
+    };
+    const int rc = run();
+    (void)hipFreeAsync(d_bad, stream);
+    if (rc != 0) return -1;
     bad_out[0] = h[0]; bad_out[1] = h[1];
     return 0;
 }
@@ -680,24 +663,33 @@ int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proo
     if (n_proofs > 65535) { set_error("h2w_check_equalities: too many proofs per call"); return -1; }
     for (uint64_t i = 0; i < 2 * n_pairs; i++) if (pairs[i] >= n_cells) { set_error("h2w_check_equalities: equality refers to a cell outside the stream"); return -1; }
     for (uint64_t i = 0; i < n_const; i++) if (const_cells[i] >= n_cells) { set_error("h2w_check_equalities: constant equality refers to a cell outside the stream"); return -1; }
+    DeviceGuard dg(device_of(advice_dev));
     hipStream_t stream = (hipStream_t)stream_;
-    uint64_t *d_pairs = nullptr, *d_cc = nullptr; fr_t *d_cv = nullptr; unsigned long long *d_bad = nullptr;
-    H2W_HIP(hipMalloc((void **)&d_pairs, (n_pairs ? 2 * n_pairs : 1) * 8)); H2W_HIP(hipMalloc((void **)&d_cc, (n_const ? n_const : 1) * 8));
-    H2W_HIP(hipMalloc((void **)&d_cv, (n_const ? n_const : 1) * sizeof(fr_t))); H2W_HIP(hipMalloc((void **)&d_bad, 16));
-    if (n_pairs) H2W_HIP(hipMemcpyAsync(d_pairs, pairs, 2 * n_pairs * 8, hipMemcpyHostToDevice, stream));
-    if (n_const) { H2W_HIP(hipMemcpyAsync(d_cc, const_cells, n_const * 8, hipMemcpyHostToDevice, stream)); H2W_HIP(hipMemcpyAsync(d_cv, const_values, n_const * sizeof(fr_t), hipMemcpyHostToDevice, stream)); }
-    H2W_HIP(hipMemsetAsync(d_bad, 0, 16, stream));
-    hipLaunchKernelGGL(k_check_equalities, dim3(1024, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, d_pairs, n_pairs, d_cc, d_cv, n_const, d_bad);
+    // one stream-ordered allocation for the three lists and the counters: nothing to leak on an error path, nothing synchronous
+    const size_t b_pairs = (n_pairs ? 2 * n_pairs : 1) * 8, b_cc = (n_const ? n_const : 1) * 8, b_cv = (n_const ? n_const : 1) * sizeof(fr_t);
+    char *d = nullptr;
+    H2W_HIP(hipMallocAsync((void **)&d, b_pairs + b_cc + b_cv + 16, stream));
+    uint64_t *d_pairs = (uint64_t *)d, *d_cc = (uint64_t *)(d + b_pairs); fr_t *d_cv = (fr_t *)(d + b_pairs + b_cc); unsigned long long *d_bad = (unsigned long long *)(d + b_pairs + b_cc + b_cv);
     unsigned long long h[2] = {0, 0};
-    H2W_HIP(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, stream));
-    H2W_HIP(hipStreamSynchronize(stream));
-    (void)hipFree(d_pairs); (void)hipFree(d_cc); (void)hipFree(d_cv); (void)hipFree(d_bad);
+    auto run = [&]() -> int {
+        if (n_pairs) H2W_HIP(hipMemcpyAsync(d_pairs, pairs, 2 * n_pairs * 8, hipMemcpyHostToDevice, stream));
+        if (n_const) { H2W_HIP(hipMemcpyAsync(d_cc, const_cells, n_const * 8, hipMemcpyHostToDevice, stream)); H2W_HIP(hipMemcpyAsync(d_cv, const_values, n_const * sizeof(fr_t), hipMemcpyHostToDevice, stream)); }
+        H2W_HIP(hipMemsetAsync(d_bad, 0, 16, stream));
+        hipLaunchKernelGGL(k_check_equalities, dim3(1024, (unsigned)n_proofs), dim3(256), 0, stream, (const fr_t *)advice_dev, proof_stride_cells, d_pairs, n_pairs, d_cc, d_cv, n_const, d_bad);
+        H2W_HIP(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, stream));
+        H2W_HIP(hipStreamSynchronize(stream));
+        return 0;
+    };
+    const int rc = run();
+    (void)hipFreeAsync(d, stream);
+    if (rc != 0) return -1;
     bad_out[0] = h[0]; bad_out[1] = h[1];
     return 0;
 }
 int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {
     if (!p || !workspace_dev || !host_status) { set_error("h2w_plan_status: null argument"); return -1; }
     size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
+    DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
     H2W_HIP(hipMemcpyAsync(host_status, (const char *)workspace_dev + o_status, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     H2W_HIP(hipStreamSynchronize(stream));
@@ -705,6 +697,7 @@ int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, u
 }
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream_) {
     if (!advice_dev || !digest4_dev) { set_error("h2w_advice_digest: null argument"); return -1; }
+    DeviceGuard dg(device_of(advice_dev));
     hipStream_t stream = (hipStream_t)stream_;
     H2W_HIP(hipMemsetAsync(digest4_dev, 0, 32, stream));
     if (n_cells) hipLaunchKernelGGL(k_digest, dim3(2048), dim3(256), 0, stream, (const ulonglong4 *)advice_dev, n_cells, (unsigned long long *)digest4_dev);
@@ -720,6 +713,7 @@ __global__ void k_to_montgomery(fr_t *cells, uint64_t n, fr_t kconst, uint64_t n
 int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream_) {
     if (!cells_dev) { set_error("h2w_advice_to_montgomery: null argument"); return -1; }
     if (n_cells == 0) return 0;
+    DeviceGuard dg(device_of(cells_dev));
     static const FrParams P = fr_params_init();
     static const fr_t K = [] { fr_t x = fr_from_u64(1); for (int i = 0; i < 256 + FR_MONT_BITS; i++) x = fr_add(x, x); return x; }();
     hipLaunchKernelGGL(k_to_montgomery, dim3(4096), dim3(256), 0, (hipStream_t)stream_, (fr_t *)cells_dev, n_cells, K, P.ninv);
@@ -729,6 +723,7 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream_) {
 int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batches before the last one (ring of 64)
     if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing: no such batch"); return -1; }
     hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
+    DeviceGuard dg(p->device);
     H2W_HIP(hipEventSynchronize(ev[6]));
     H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));   // prologue strands
     H2W_HIP(hipEventElapsedTime(&ms[1], ev[1], ev[2]));   // query glue strands (+ Goldilocks-Poseidon Merkle strands)

@@ -14,7 +14,7 @@ namespace h2w {
 
 constexpr int SPONGE_WIDTH = 12, SPONGE_RATE = 8, HALF_N_FULL_ROUNDS = 4, N_PARTIAL_ROUNDS = 22, NUM_HASH_OUT_ELTS = 4;
 constexpr int BN_WIDTH = 4, BN_RATE = 3, BN_FULL_ROUNDS = 8, BN_PARTIAL_ROUNDS = 56;
-constexpr int MAX_STEPS = 8, MAX_ARITY = 16, MAX_CAP = 64, MAX_BATCH_POLYS = 16, MAX_FINAL_POLY = 128;
+constexpr int MAX_STEPS = 8, MAX_ARITY = 16, MAX_CAP = 16, MAX_BATCH_POLYS = 16, MAX_FINAL_POLY = 128;
 enum { PRE_NONE = 0, PRE_A = 1, PRE_B = 2 };
 
 // shape-derived quantities (plonky2 FriParams)
@@ -302,34 +302,6 @@ template <class B> struct PoseidonBN254PermutationChip {
         }
     }
 };
-
-// value-domain BN254 Poseidon (same schedule as the chip above), Montgomery form throughout: used by the Merkle
-// chain strands, which only need each permutation's OUTPUT state.  `km` holds the constants in Montgomery form.
-HNI inline void bn_poseidon_native(fr_t *st /*canonical in/out*/, const h2w_poseidon_consts_t *km, const FrParams &P) {
-    fr_t s[BN_WIDTH];
-    for (int i = 0; i < BN_WIDTH; i++) s[i] = fr_mont_mul(st[i], P.r2, P.ninv);
-    auto exp5 = [&](const fr_t &x) { fr_t x2 = fr_mont_mul(x, x, P.ninv), x4 = fr_mont_mul(x2, x2, P.ninv); return fr_mont_mul(x4, x, P.ninv); };
-    auto ark = [&](int it) { for (int i = 0; i < BN_WIDTH; i++) s[i] = fr_add(s[i], km->bn_c[it + i]); };
-    auto mix = [&](const h2w_fr_t (*m)[4]) {
-        fr_t ns[BN_WIDTH];
-        for (int i = 0; i < BN_WIDTH; i++) { ns[i] = fr_zero(); for (int j = 0; j < BN_WIDTH; j++) ns[i] = fr_add(ns[i], fr_mont_mul(m[j][i], s[j], P.ninv)); }
-        for (int i = 0; i < BN_WIDTH; i++) s[i] = ns[i];
-    };
-    ark(0);
-    for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); ark((r + 1) * BN_WIDTH); mix(km->bn_m); }
-    for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); ark((BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(km->bn_p);
-    for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-        s[0] = fr_add(exp5(s[0]), km->bn_c[(BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r]);
-        fr_t ns0 = fr_zero();
-        for (int j = 0; j < BN_WIDTH; j++) ns0 = fr_add(ns0, fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + j], s[j], P.ninv));
-        for (int kk = 1; kk < BN_WIDTH; kk++) s[kk] = fr_add(s[kk], fr_mont_mul(km->bn_s[(BN_WIDTH * 2 - 1) * r + BN_WIDTH + kk - 1], s[0], P.ninv));
-        s[0] = ns0;
-    }
-    for (int r = 0; r < BN_FULL_ROUNDS / 2 - 1; r++) { for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); ark((BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH); mix(km->bn_m); }
-    for (int i = 0; i < BN_WIDTH; i++) s[i] = exp5(s[i]); mix(km->bn_m);
-    fr_t one = fr_from_u64(1);
-    for (int i = 0; i < BN_WIDTH; i++) st[i] = fr_mont_mul(s[i], one, P.ninv);
-}
 
 // =========================================================================== HasherChip (hash/mod.rs:52-127; hash/poseidon/hash.rs; hash/poseidon_bn254/hash.rs)
 template <class B> struct HashW { typename B::Gl e[4]; typename B::Fr f; };   // PoseidonHashWire (e) / PoseidonBN254HashWire (f)

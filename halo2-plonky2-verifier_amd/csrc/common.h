@@ -12,6 +12,23 @@ extern thread_local std::string g_last_error;
 #define H2W_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     h2w::set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return -1; } } while (0)
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the guard (a caller that drives several GPUs from
+// one thread must not have to bracket every call with hipSetDevice); -1 = leave as is.  device_of: the device a pointer lives on.
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete; DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+inline int device_of(const void *ptr) {
+    hipPointerAttribute_t a;
+    if (!ptr || hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return a.type == hipMemoryTypeDevice ? a.device : -1;
+}
+
 // arguments of the expansion kernel (expand.hip)
 struct ExpandArgs {
     const uint64_t *meta;      // [nrec] template id << 56 | first cell offset (per proof, shared by the batch)

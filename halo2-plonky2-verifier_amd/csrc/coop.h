@@ -42,14 +42,15 @@ __device__ __forceinline__ uint64_t gl_add_c(uint64_t x, uint64_t y) {   // cano
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) { return __shfl_up(v, d, 64); }
 
 template <bool COLS> struct CoopSinkT {
-    static constexpr bool kCoop = true;
+    static constexpr bool kCoop = true, kSplitOnly = false;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; int dbg_skip_perm = 0; ColPolicy<COLS> cc;
+    bool emit = true;            // false: values only (a sharded run computes every prologue for its challenges, but only the owning rank emits it)
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-        if (lane == 0) g_store_rec(recs + nrec, a, b, c, d);
+        if (lane == 0 && emit) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
     bool lane_mode = false, lane_on = false;     // lane_mode: every enabled lane writes cells at its OWN offset (coop_decompose_hashes)
-    __device__ __forceinline__ void cell(const fr_t &v) { if (lane_mode ? lane_on : lane == 0) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if ((lane_mode ? lane_on : lane == 0) && emit) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
     __device__ int coop_lanes() { return 64; }
@@ -75,9 +76,9 @@ template <bool COLS> struct CoopSinkT {
             const uint64_t wk = g_load_u64(ip), irec = g_load_u64(ip + 1), icell = g_load_u64(ip + 2);
             const uint32_t word = (uint32_t)wk, kind = (uint32_t)(wk >> 32);
             const uint64_t *w = cfg.proof + word; const uint64_t w0 = g_load_u64(w);
-            if (kind <= 1) { g_store_rec(recs + irec, w0, 0, 0, 0); bad |= w0 >= GL_P; }
-            else if (kind == 2) { const uint64_t w1 = g_load_u64(w + 1), w2 = g_load_u64(w + 2), w3 = g_load_u64(w + 3); g_store_rec(recs + irec, w0, w1, w2, w3); bad |= w0 >= GL_P || w1 >= GL_P || w2 >= GL_P || w3 >= GL_P; }
-            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); g_store_fr(out + cc.map(icell), v); bad |= fr_geq_mod(v); }
+            if (kind <= 1) { if (emit) g_store_rec(recs + irec, w0, 0, 0, 0); bad |= w0 >= GL_P; }
+            else if (kind == 2) { const uint64_t w1 = g_load_u64(w + 1), w2 = g_load_u64(w + 2), w3 = g_load_u64(w + 3); if (emit) g_store_rec(recs + irec, w0, w1, w2, w3); bad |= w0 >= GL_P || w1 >= GL_P || w2 >= GL_P || w3 >= GL_P; }
+            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); if (emit) g_store_fr(out + cc.map(icell), v); bad |= fr_geq_mod(v); }
         }
         if (__any(bad)) load_flag = 4;
         nrec += cfg.load_nrec; cell_off += cfg.load_ncell;
@@ -93,7 +94,8 @@ template <bool COLS> struct CoopSinkT {
             return;
         }
         const int l = lane, grp13 = lane / 13, idx13 = lane % 13;
-        auto W = [&](int idx, uint64_t A, uint64_t B, uint64_t C) { g_store_rec(R + idx, A, B, C, 0); };
+        const bool em = emit;
+        auto W = [&](int idx, uint64_t A, uint64_t B, uint64_t C) { if (em) g_store_rec(R + idx, A, B, C, 0); };
         if (l < SPONGE_WIDTH) s_a[l] = st[l];
         wave_sync();
         int base = 0, round_ctr = 0;
@@ -297,7 +299,7 @@ constexpr BnSrc bn_map_partial(int c) {
 }
 
 template <bool COLS> struct QuadSinkT {
-    static constexpr bool kCoop = false;
+    static constexpr bool kCoop = false, kSplitOnly = false;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4; ColPolicy<COLS> cc;
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (l4 == 0) g_store_rec(recs + nrec, a, b, c, d);

@@ -11,6 +11,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <atomic>
 #include "records.h"
 #include "common.h"
 #include "keygen.h"
@@ -20,7 +21,7 @@ namespace h2w {
 
 thread_local std::string g_last_error;
 void set_error(const std::string &s) { g_last_error = s; }
-static uint32_t g_next_ctx_id = 1;
+static std::atomic<uint32_t> g_next_ctx_id{1};      // contexts may be created from several threads
 
 }  // namespace h2w
 
@@ -185,6 +186,7 @@ h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id) {
 }
 void h2w_ctx_free(h2w_ctx *c) {
     if (!c) return;
+    DeviceGuard dg(c->d_out || c->d_meta || c->dt.slots ? c->device : -1);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_meta) hipFree(c->d_meta);
     if (c->d_recs) hipFree(c->d_recs);
@@ -418,7 +420,7 @@ static int ensure_expanded(h2w_ctx *c) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, "h2w: no HIP device visible — the advice stream is only produced on the GPU (no CPU fallback)");
     if (c->device >= ndev) return fail(c, "h2w: device_id out of range");
-    H2W_HIP(hipSetDevice(c->device));
+    DeviceGuard dg(c->device);
     if (c->d_out) { hipFree(c->d_out); c->d_out = nullptr; }
     if (c->d_meta) { hipFree(c->d_meta); c->d_meta = nullptr; }
     if (c->d_recs) { hipFree(c->d_recs); c->d_recs = nullptr; }
@@ -458,6 +460,7 @@ int h2w_ctx_download(h2w_ctx *c, uint64_t first, uint64_t count, h2w_fr_t *host_
     if (first + count > c->ncells) return fail(c, "h2w_ctx_download: range out of bounds");
     if (ensure_expanded(c) != 0) return -1;
     if (count == 0) return 0;
+    DeviceGuard dg(c->device);
     H2W_HIP(hipMemcpy(host_dst, (const fr_t *)c->d_out + first, count * sizeof(fr_t), hipMemcpyDeviceToHost));
     return 0;
 }

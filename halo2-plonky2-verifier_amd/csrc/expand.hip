@@ -62,12 +62,12 @@ template <int TILE_RECS, int NSTEP, bool COLS = false> __global__ __launch_bound
         if (tid < TILE_RECS) {
             uint32_t n = 0;
             bool mine = tid < nr;
-            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block is kept by every rank
+            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block belongs to rank proof mod world
                 const uint64_t r = r0 + tid;
                 if (r >= A.q_rec0_first) {
                     const uint64_t q = r < A.q_rec0_rest ? 0 : 1 + (r - A.q_rec0_rest) / A.q_nrec_rest;
                     mine = (proof * A.nq + q) % A.shard_world == A.shard_rank;
-                }
+                } else mine = proof % A.shard_world == A.shard_rank;      // prologue block: the proof's owner
             }
             if (mine) {
                 const uint64_t m = A.meta[r0 + tid];
@@ -263,12 +263,12 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
             const uint64_t r0 = (uint64_t)tile * 64 + (uint64_t)pass * FAST_T;
             if (r0 >= A.nrec) break;
             bool mine = lane < FAST_T && r0 + (uint64_t)lane < A.nrec;
-            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block is kept by every rank
+            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block belongs to rank proof mod world
                 const uint64_t r = r0 + lane;
                 if (r >= A.q_rec0_first) {
                     const uint64_t q = r < A.q_rec0_rest ? 0 : 1 + (r - A.q_rec0_rest) / A.q_nrec_rest;
                     mine = (proof * A.nq + q) % A.shard_world == A.shard_rank;
-                }
+                } else mine = proof % A.shard_world == A.shard_rank;      // prologue block: the proof's owner
             }
             uint32_t t = T_LITERAL; rec_t rc; rc.a = rc.b = rc.c = rc.d = 0; ull coff = 0;
             if (mine) { const uint64_t m = A.meta[r0 + lane]; rc = recs[r0 + lane]; t = meta_tmpl(m); coff = meta_off(m); }

@@ -10,7 +10,14 @@
 #define HD __host__ __device__ __forceinline__
 #define HDN __host__ __device__
 #define HF __host__ __device__ inline
+// HNI: out-of-line by default (the gadget stack is instantiated over five backends; code size).  A translation unit that
+// defines H2W_FLATTEN_CHIPS gets them inlinable: its kernel is then flattened so that the sink state lives in registers - every
+// AMDGPU function call starts with s_waitcnt vmcnt(0) and reaches its object through flat loads (see glue.hip).
+#if defined(H2W_FLATTEN_CHIPS)
+#define HNI __host__ __device__ inline
+#else
 #define HNI __host__ __device__ __attribute__((noinline))
+#endif
 #else
 #define HD inline
 #define HDN

@@ -1,0 +1,38 @@
+// glue.hip - the query glue strands of the batched hot path: FriChip::verify_query_round minus its Merkle proofs
+// (fri/mod.rs:338-444: index bits, subgroup_x, combine_initial, per fold step the consistency select, compute_evaluation /
+// interpolate_coset and x^arity, final-polynomial evaluation), one lane per (proof, query).
+//
+// Its own translation unit because the gadget stack is compiled FLATTENED here (H2W_FLATTEN_CHIPS): a strand is a serial program of
+// a few thousand Goldilocks ops, each of which appends one 32-byte block record.  Out of line, every op is an AMDGPU function call:
+// it starts with s_waitcnt vmcnt(0) - i.e. it waits for the record store of the PREVIOUS op to be acknowledged by memory - and
+// reaches the sink's cursor (record index, cell offset) through flat loads of the backend object (profiles/: 5.3 ms for 5.5 k ops
+// per lane, ~1 us per op).  Flattened, the cursor lives in registers and nothing waits for a store.
+#define H2W_FLATTEN_CHIPS 1
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "batchargs.h"
+
+namespace h2w {
+
+template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_strands(BatchArgs A) {
+    typedef DevSinkT<COLS, true> GlueSink; typedef ValBackend<GlueSink> GlueB;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = A.shape.num_queries;
+    if (idx >= A.nproofs * nq) return;
+    const int p = idx / nq, q = idx % nq;
+    if (!own_unit(A, p, q)) return;
+    GlueSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
+    sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
+    const ChallengeBlock<GlueB> &cb = *reinterpret_cast<const ChallengeBlock<GlueB> *>(&A.cbs[p]);
+    GlueB be(sink, make_cfg(A, p), true);
+    Verifier<GlueB> V(be, A.shape, A.consts);
+    V.query_round(q, cb);
+    if (be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+
+void launch_glue_strands(const BatchArgs &A, unsigned nlanes, hipStream_t stream) {
+    if (A.cm.starts) hipLaunchKernelGGL(k_strands<true>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+    else hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
+}
+
+}  // namespace h2w

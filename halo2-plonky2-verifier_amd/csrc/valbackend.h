@@ -44,6 +44,7 @@ struct ValCfg {
 template <class Sink> struct ValBackend {
     typedef uint64_t Gl; typedef uint64_t Bool; typedef fr_t Fr; typedef u128 Big;
     static constexpr bool kCoopPoseidon = Sink::kCoop;
+    static constexpr bool kSplitOnly = Sink::kSplitOnly;       // the backend only ever runs strands whose Merkle proofs are other strands
     Sink &sink; ValCfg cfg; bool zero_cached; uint32_t status; uint64_t unit_idx = 0;
     HF void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *k) { sink.coop_poseidon_permute(st, k); }
     HF ValBackend(Sink &s, const ValCfg &c, bool zero_cached_) : sink(s), cfg(c), zero_cached(zero_cached_), status(0) {}
@@ -221,8 +222,8 @@ template <class Sink> struct ValBackend {
 };
 
 // device sink: records into this proof's record array, direct cells into this proof's advice range
-template <bool COLS> struct DevSinkT {
-    static constexpr bool kCoop = false;
+template <bool COLS, bool SPLIT_ONLY = false> struct DevSinkT {
+    static constexpr bool kCoop = false, kSplitOnly = SPLIT_ONLY;
     HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; ColPolicy<COLS> cc;
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }

@@ -159,8 +159,11 @@ template <class B> struct Verifier {
         }
     }
     HF void merkle_call(int q, int kind, const Bool *bits, int n_bits, Gl cap_index) {
-        if (be.merkle_split(q, kind)) return;      // device: cells of this call belong to a merkle strand
-        be.merkle_begin(q, kind); merkle_strand(q, kind, bits, n_bits, cap_index); be.merkle_end(q, kind);
+        if constexpr (B::kSplitOnly) { be.merkle_split(q, kind); return; }      // glue strands: the cells of this call belong to a merkle strand
+        else {
+            if (be.merkle_split(q, kind)) return;
+            be.merkle_begin(q, kind); merkle_strand(q, kind, bits, n_bits, cap_index); be.merkle_end(q, kind);
+        }
     }
     // ---- FriChip pieces (fri/mod.rs)
     HNI Ex combine_initial(int q, const ChallengeBlock<B> &cb, Gl subgroup_x) {                       // :169-220

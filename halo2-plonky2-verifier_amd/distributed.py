@@ -1,6 +1,6 @@
-"""Multi-GPU plumbing for the batched hot path: the path shards by proof with no data-path collective.
-One process per GPU; the ONLY collective is one broadcast of the flat proof block from the ingest rank
-(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+"""Multi-GPU plumbing for the batched hot path: the path shards by proof - or, for few large proofs, by (proof, query)
+unit - with no data-path collective.  One process per GPU; the ONLY collective is one broadcast of the flat proof block from
+the ingest rank (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
 import torch
 import torch.distributed as dist
 
@@ -34,3 +34,29 @@ def unit_owner(proof, query, num_queries, world):
 
 def my_units(n_proofs, num_queries, rank, world):
     return [(p, q) for p in range(n_proofs) for q in range(num_queries) if unit_owner(p, q, num_queries, world) == rank]
+
+
+def prologue_owner(proof, world):
+    """The rank that EMITS the prologue block of a proof in a query-sharded run (every rank computes its values)."""
+    return proof % world
+
+
+def shard_cells(n_proofs, num_queries, rank, world, prologue_cells, query_cells_first, query_cells_rest):
+    """Advice cells rank `rank` writes in a query-sharded run of n_proofs proofs: its query blocks (query 0 of a context holds the one
+    cached load_zero cell more than the others) plus the prologue blocks it owns.  The shares of all ranks add up to the stream."""
+    cells = sum(query_cells_first if q == 0 else query_cells_rest for _, q in my_units(n_proofs, num_queries, rank, world))
+    return cells + prologue_cells * sum(1 for p in range(n_proofs) if prologue_owner(p, world) == rank)
+
+
+def shard_ranges(n_proofs, num_queries, rank, world, layout):
+    """Cell ranges (proof, first cell, length) that rank `rank` writes in a query-sharded run; `layout` = Plan.strand_layout()."""
+    pro, q0, qn, total = layout
+    assert pro + q0 + (num_queries - 1) * qn == total
+    out = []
+    for p in range(n_proofs):
+        if prologue_owner(p, world) == rank:
+            out.append((p, 0, pro))
+        for q in range(num_queries):
+            if unit_owner(p, q, num_queries, world) == rank:
+                out.append((p, pro, q0) if q == 0 else (p, pro + q0 + (q - 1) * qn, qn))
+    return out

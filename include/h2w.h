@@ -16,7 +16,9 @@
  * Plain C: pointers and sizes only, no C++/torch types.  All functions returning int return 0 on
  * success; on failure h2w_last_error() describes it (the reference panics instead; the Rust shim
  * in INTEGRATION.md converts non-zero to panic!).  Handles are not thread-safe; distinct handles
- * are independent (the reference is single-threaded: one &mut Context).
+ * are independent (the reference is single-threaded: one &mut Context) and carry their device: a call
+ * makes the handle's device current for its own duration (functions without a handle use the device their
+ * device pointer lives on), so one thread can drive plans on several GPUs.
  *
  * Advice cells are BN254 Fr values, 32 bytes each, canonical little-endian (4 x u64 limbs).
  */
@@ -225,11 +227,17 @@ int h2w_check_constraints(h2w_plan *, const void *advice_dev, uint64_t proof_str
 
 /* (proof, query) sharding across the GPUs of a node (north star: "independent FRI queries and Merkle paths sharded across
  * the 8 GPUs"): rank r of `world` generates, at their global offsets in its own advice_dev[n_proofs][num_cells], the prologue
- * block of every proof (witness load, challenger, PoW, reduced openings: needed for the challenges anyway) and the query blocks
- * of the units (proof * num_queries + query) % world == r; the other query blocks are not touched.  No collective on the data
- * path: every rank needs the proofs (one broadcast) and nothing else.  The byte-wise union over the ranks is the full stream. */
+ * block of the proofs it owns (proof % world == r: witness load, challenger, PoW, reduced openings - every rank computes the
+ * VALUES of every prologue, it needs the challenges, but only the owner emits the cells) and the query blocks of the units
+ * (proof * num_queries + query) % world == r; the other blocks are not touched.  No collective on the data path: every rank
+ * needs the proofs (one broadcast) and nothing else.  The ranks' blocks are disjoint and their union is the full stream. */
 int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev,
                                 void *stream, int rank, int world);
+/* The block structure of a proof's cell stream that the sharding above follows (static per shape; no device needed):
+ * out[0] = cells of the prologue block [0, out[0]); out[1] = cells of query block 0 (it holds the Context's one cached load_zero
+ * cell when that falls into a query); out[2] = cells of every later query block; out[3] = cells per proof
+ * (= out[0] + out[1] + (num_queries - 1) * out[2]). */
+int h2w_plan_strand_layout(const h2w_plan *, uint64_t out[4]);
 /* The rest of the restated MockProver: copy constraints (bad[0] = pairs whose two cells differ) and constant equalities (bad[1])
  * over device advice streams.  The lists are static per shape: take them from an eager keygen context of the same shape
  * (h2w_ctx_equalities / h2w_ctx_const_equalities).  Synchronises the stream. */
@@ -261,6 +269,9 @@ int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
 int h2w_plan_last_timing(h2w_plan *, float ms[5]);
 /* Advice cells per proof written by the expansion kernel (the rest are written directly by the value kernels). */
 uint64_t h2w_plan_num_record_cells(const h2w_plan *);
+/* Advice cells per proof of the MerkleTreeChip::verify_proof_to_cap_with_cap_index calls (merkle/mod.rs:57-78): with PoseidonBN254
+ * caps these are the cells the chain kernel writes itself (its permutations' 4,032 cells each, the selects, the cap lookup). */
+uint64_t h2w_plan_num_chain_cells(const h2w_plan *);
 
 /* ------------------------------------------------------------------ the step BEFORE the path
  * Synthetic VALID FRI instances generated on the GPU (SURVEY 8(d) variant (A)): low-degree extension (Goldilocks NTT on the coset

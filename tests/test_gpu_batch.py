@@ -185,9 +185,9 @@ def test_noncanonical_proof_words_are_flagged(h2w, h2w_api, oracle, consts, mode
 
 @pytest.mark.parametrize("mode", [1, 0])
 def test_query_sharding_union_is_the_full_stream(h2w, h2w_api, oracle, consts, mode):
-    """(proof, query) units dealt round-robin to the ranks.  Each rank's buffer holds the prologue and its own query
-    blocks only (the rest stays as it was: zero here); the query blocks of different ranks are disjoint and their union with the
-    prologue is byte-for-byte the oracle's stream."""
+    """(proof, query) units dealt round-robin to the ranks, the prologue block of a proof to rank proof mod world (every
+    rank still computes every prologue's VALUES: it needs the challenges).  A rank's buffer holds its own blocks only (the rest
+    stays as it was: zero here); the blocks of different ranks are disjoint and their union is byte-for-byte the oracle's stream."""
     import numpy as np
     import torch
     D = importlib_distributed()
@@ -215,27 +215,27 @@ def test_query_sharding_union_is_the_full_stream(h2w, h2w_api, oracle, consts, m
         assert oracle.verify_stark(ctx, osh, ko, p) == 0
         want.append(np.frombuffer(ctx.advice_bytes(), dtype=np.int64).reshape(plan.num_cells, 4)); ctx.close()
     want = np.stack(want)
-    # where does the prologue end?  every rank wrote it identically; beyond it the ranks' non-zero cells are disjoint
     union = np.zeros_like(want)
     touched = np.zeros((n, plan.num_cells), dtype=np.int32)
     for part in parts:
-        nz = (part != 0).any(axis=2)
-        touched += nz
+        touched += (part != 0).any(axis=2)
         union |= part
     assert (union == want).all()
-    # every cell is non-zero on all ranks (prologue block), on exactly one (a query block of that rank) or nowhere (a zero-valued cell)
-    assert set(np.unique(touched)) <= {0, 1, world}
+    assert set(np.unique(touched)) <= {0, 1}              # every non-zero cell has exactly one writer: the ranks' blocks are disjoint
     nq = sh.num_queries
-    for rank, part in enumerate(parts):
-        alone = ((part != 0).any(axis=2)) & (touched == 1)          # cells only this rank wrote
+    wrote = [((part != 0).any(axis=2)) for part in parts]
+    for rank in range(world):
         mine = D.my_units(n, nq, rank, world)
-        assert alone.sum() > 0 and len(mine) in (n * nq // world, n * nq // world + 1)
-        # a rank that owns no unit of a proof writes nothing of it beyond the prologue
-        for p_ in range(n):
-            if not any(pp == p_ for pp, _ in mine):
-                assert alone[p_].sum() == 0
-    per_rank = [int((((part != 0).any(axis=2)) & (touched == 1)).sum()) for part in parts]
-    assert max(per_rank) < 2 * min(per_rank)                          # query blocks have (nearly) equal size: the shares are balanced
+        assert wrote[rank].sum() > 0 and len(mine) in (n * nq // world, n * nq // world + 1)
+        for p_ in range(n):      # a rank that owns neither a unit nor the prologue of a proof writes nothing of it
+            if not any(pp == p_ for pp, _ in mine) and D.prologue_owner(p_, world) != rank:
+                assert wrote[rank][p_].sum() == 0
+    # the prologue block (the cells before the first query block) of proof p comes from rank p mod world alone
+    first_query_cell = min(int(np.argmax(wrote[r][0])) for r in range(world) if r != D.prologue_owner(0, world) and wrote[r][0].any())
+    assert wrote[D.prologue_owner(0, world)][0][:first_query_cell].sum() > 0
+    for r in range(world):
+        if r != D.prologue_owner(0, world):
+            assert wrote[r][0][:first_query_cell].sum() == 0
     plan.close()
 
 

@@ -73,3 +73,70 @@ def test_query_unit_partition_is_exact():
         flat = [u for s_ in shares for u in s_]
         assert sorted(flat) == [(p, q) for p in range(n_proofs) for q in range(nq)]
         assert max(map(len, shares)) - min(map(len, shares)) <= 1
+
+
+def _shard_worker(rank, world, port, n, out):
+    """One rank of a query-sharded run, on the CPU: the broadcast, the host-side partition (Plan.strand_layout + shard_ranges:
+    what h2w_fri_witness_batch_shard's kernels follow on the device) and this rank's cells - cut out of the oracle's stream, which
+    stands in for the device here - gathered over gloo."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import importlib
+    import pyoracle as O
+    h2w = importlib.import_module("halo2-plonky2-verifier_amd")
+    api = importlib.import_module("halo2-plonky2-verifier_amd.api")
+    D = importlib.import_module("halo2-plonky2-verifier_amd.distributed")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    osh = O.fibonacci_shape(6, 3, hash_mode=1); sh = h2w.fibonacci_shape(6, 3, hash_mode=1)
+    plan = api.Plan(sh, h2w.published_consts())           # layout queries only: no device is touched (and none exists in this test)
+    words = plan.proof_words
+    proofs = torch.zeros(n * words, dtype=torch.int64)
+    if rank == 0:
+        for i in range(n):
+            proofs[i * words:(i + 1) * words] = torch.frombuffer(bytearray(bytes(O.synth_proof(osh, 700 + i))), dtype=torch.int64)
+    D.broadcast_proofs(proofs, src=0)
+    ko = O.published_consts()
+    mine = torch.zeros(n * plan.num_cells * 4, dtype=torch.int64).view(n, plan.num_cells, 4)
+    wrote = torch.zeros(n, plan.num_cells, dtype=torch.int32)
+    ranges = D.shard_ranges(n, sh.num_queries, rank, world, plan.strand_layout())
+    for p in sorted({r[0] for r in ranges}):
+        ctx = O.Ctx(21)
+        pw = (O.C.c_uint64 * words).from_buffer(bytearray(proofs[p * words:(p + 1) * words].numpy().tobytes()))
+        assert O.verify_stark(ctx, osh, ko, pw) == 0
+        full = torch.frombuffer(bytearray(ctx.advice_bytes()), dtype=torch.int64).view(plan.num_cells, 4); ctx.close()
+        for pp, first, length in ranges:
+            if pp == p:
+                mine[p, first:first + length] = full[first:first + length]; wrote[p, first:first + length] += 1
+    cells = int(wrote.sum().item())
+    assert cells == sum(r[2] for r in ranges) == D.shard_cells(n, sh.num_queries, rank, world, *plan.strand_layout()[:3])
+    dist.all_reduce(wrote, op=dist.ReduceOp.SUM)          # how many ranks wrote each cell
+    dist.all_reduce(mine, op=dist.ReduceOp.SUM)           # disjoint writers -> the sum IS the union
+    if rank == 0:
+        ok = bool((wrote == 1).all().item())
+        want = []
+        for p in range(n):
+            ctx = O.Ctx(21)
+            pw = (O.C.c_uint64 * words).from_buffer(bytearray(proofs[p * words:(p + 1) * words].numpy().tobytes()))
+            assert O.verify_stark(ctx, osh, ko, pw) == 0
+            want.append(torch.frombuffer(bytearray(ctx.advice_bytes()), dtype=torch.int64).view(plan.num_cells, 4)); ctx.close()
+        out.put((ok, bool((torch.stack(want) == mine).all().item()), cells))
+    else:
+        out.put((True, True, cells))
+    plan.close()
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_query_sharded_witness_union_over_two_ranks():
+    """world_size 2 over gloo: every cell of every proof is produced by exactly one rank and the union is the oracle's stream."""
+    world, n = 2, 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + ((os.getpid() + 7) % 500)
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, n, out)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [out.get(timeout=300) for _ in range(world)]
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(r[0] and r[1] for r in res)
+    shares = sorted(r[2] for r in res)
+    assert shares[0] > 0 and shares[1] < 2 * shares[0]      # both ranks carry a real share
