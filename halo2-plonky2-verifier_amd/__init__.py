@@ -158,6 +158,15 @@ SYMBOLS = {
     "h2w_plan_configure": (C.c_int, [_vp, C.c_int, C.c_int]),
     "h2w_plan_num_chain_cells": (C.c_uint64, [_vp]),
     "h2w_plan_strand_layout": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "h2w_plan_num_equalities": (C.c_uint64, [_vp]),
+    "h2w_plan_num_const_equalities": (C.c_uint64, [_vp]),
+    "h2w_plan_equalities": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "h2w_plan_const_equalities": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), _vp]),
+    "h2w_chipbatch_new": (_vp, [C.c_int, C.c_int, C.c_int]),
+    "h2w_chipbatch_free": (None, [_vp]),
+    "h2w_chipbatch_num_operands": (C.c_uint64, [_vp]),
+    "h2w_chipbatch_num_cells": (C.c_uint64, [_vp]),
+    "h2w_chipbatch_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
     "h2w_plan_timing": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
     "h2w_plan_num_record_cells": (C.c_uint64, [_vp]),
     "h2w_prover_new": (_vp, [C.POINTER(Shape), C.POINTER(PoseidonConsts), C.c_int]),

@@ -234,6 +234,24 @@ class Plan:
         else:
             _ck(self.L.h2w_fri_witness_batch2(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, emit_stream), "h2w_fri_witness_batch2")
 
+    def advice_digest(self, advice_ptr, n_cells, digest_ptr, stream=0):
+        """32-byte checksum of n_cells cells at advice_ptr into 4 u64 at digest_ptr (device) — h2w_advice_digest."""
+        _ck(self.L.h2w_advice_digest(advice_ptr, n_cells, digest_ptr, stream), "h2w_advice_digest")
+
+    def equalities(self):
+        """Copy constraints of the plan's cell stream: [(cell a, cell b), ...] (h2w_plan_equalities)."""
+        n = int(self.L.h2w_plan_num_equalities(self.p))
+        buf = (C.c_uint64 * max(2 * n, 1))()
+        _ck(self.L.h2w_plan_equalities(self.p, buf), "h2w_plan_equalities")
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+    def const_equalities(self, proof_words=None):
+        """Constant equalities [(cell, value), ...] (h2w_plan_const_equalities); proof_words: needed with Goldilocks-Poseidon caps."""
+        n = int(self.L.h2w_plan_num_const_equalities(self.p))
+        cells = (C.c_uint64 * max(n, 1))(); vals = (Fr * max(n, 1))()
+        _ck(self.L.h2w_plan_const_equalities(self.p, proof_words, cells, vals), "h2w_plan_const_equalities")
+        return [(int(cells[i]), vals[i].to_int()) for i in range(n)]
+
     def strand_layout(self):
         """(prologue cells, cells of query block 0, cells of a later query block, cells per proof) — h2w_plan_strand_layout."""
         out = (C.c_uint64 * 4)()
@@ -369,3 +387,18 @@ class Prover:
         ms = (C.c_float * 7)()
         _ck(self.L.h2w_prover_timing(self.p, ms), "h2w_prover_timing")
         return dict(zip(("lde", "commit", "openings_quotient", "fri_commit", "pow", "queries", "total_wall"), [float(x) for x in ms]))
+
+
+def advice_digest_reference(cells_bytes, chunk_cells=1 << 22):
+    """The checksum h2w_advice_digest computes (include/h2w.h), restated with numpy over a host copy of a cell stream: limb j of cell i
+    is weighted by ((i + 1) * 0x9E3779B97F4A7C15 | 1) + 2 j, sums mod 2^64 per limb position."""
+    import numpy as np
+    c = cells_bytes if isinstance(cells_bytes, np.ndarray) else np.frombuffer(cells_bytes, dtype=np.uint64).reshape(-1, 4)
+    acc = [0, 0, 0, 0]
+    with np.errstate(over="ignore"):
+        for lo in range(0, c.shape[0], chunk_cells):
+            part = c[lo:lo + chunk_cells]
+            m = (np.arange(lo + 1, lo + part.shape[0] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+            for j in range(4):
+                acc[j] = (acc[j] + int((part[:, j] * (m + np.uint64(2 * j))).sum(dtype=np.uint64))) & 0xFFFFFFFFFFFFFFFF
+    return acc

@@ -6,6 +6,7 @@
 // hash/*/hash.rs test_hash_no_pad / test_hash_two_to_one, merkle/mod.rs:136-265, stark/mod.rs:405-518) so the parity
 // tests read like them.  Cells still come only from the GPU expansion kernel.
 #include <vector>
+#include <map>
 #include <string>
 #include <cstring>
 #include "common.h"
@@ -171,6 +172,81 @@ int h2w_chip_verify_stark(h2w_ctx *ctx, const h2w_shape_t *shape, const h2w_pose
     V.run_all(*cb);
     delete cb;
     return finish(be, "h2w_chip_verify_stark");
+}
+
+
+// ---- copy constraints and constant equalities of a PLAN's cell stream (SURVEY 8f row 2 for the batched path).  The batched kernels
+// compute on values, not on cell handles, so the lists come from a replay of the shape through the eager keygen context (whose
+// handles carry cell offsets: field/native.rs:185-193 constrain_equal, Context::assign_region's copies) - static per shape, host only,
+// built once and cached in the plan.  The proof the replay runs on only has to keep the reference's assertions quiet (non-zero
+// denominators): words of a fixed pseudo-random sequence, every one a canonical field element.
+static void replay_words(std::vector<uint64_t> &words, uint64_t seed) {
+    uint64_t x = seed;
+    for (uint64_t &w : words) { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; w = (z ^ (z >> 31)) >> 4; }      // < 2^60
+}
+static int plan_replay(h2w_plan *p, const std::vector<uint64_t> &words, std::vector<uint64_t> *pairs, std::vector<uint64_t> &cells, std::vector<fr_t> &values) {
+    const h2w_shape_t &sh = plan_shape(p);
+    h2w_ctx *c = h2w_ctx_new(sh.lookup_bits, 0, -1);
+    if (!c) return -1;
+    int rc = h2w_chip_verify_stark(c, &sh, &plan_consts(p), words.data());
+    if (rc == 0 && h2w_num_cells(c) != plan_cells(p)) { set_error("h2w_plan_equalities: internal: replay length mismatch"); rc = -1; }
+    if (rc == 0) {
+        if (pairs) { pairs->resize(2 * h2w_ctx_num_equalities(c)); if (!pairs->empty() && h2w_ctx_equalities(c, pairs->data()) != 0) rc = -1; }
+        cells.resize(h2w_ctx_num_const_equalities(c)); values.resize(cells.size());
+        if (rc == 0 && !cells.empty() && h2w_ctx_const_equalities(c, cells.data(), values.data()) != 0) rc = -1;
+    }
+    h2w_ctx_free(c);
+    return rc;
+}
+static int plan_equalities_build(h2w_plan *p) {
+    PlanEqualities &E = plan_equalities(p);
+    if (E.ready) return 0;
+    const h2w_shape_t &sh = plan_shape(p);
+    Derived d = derive_shape(sh); ProofLayout pl = proof_layout(sh, d);
+    std::vector<uint64_t> wa(pl.total), wb(pl.total);
+    replay_words(wa, 0x9E3779B97F4A7C15ull); replay_words(wb, 0xD1B54A32D192ED03ull);
+    std::vector<uint64_t> cells_b; std::vector<fr_t> values_b;
+    int rc = plan_replay(p, wa, &E.pairs, E.const_cells, E.const_values);
+    // the constants that ARE proof words (the reference loads Goldilocks-Poseidon hash wires as constants, hash/poseidon/hash.rs:86-96):
+    // the cells whose constant changes with the proof; a second replay on other words finds them and which word each one holds
+    if (rc == 0 && sh.hash_mode == 0) rc = plan_replay(p, wb, nullptr, cells_b, values_b);
+    if (rc == 0) {
+        E.const_word.assign(E.const_cells.size(), -1);
+        if (sh.hash_mode == 0) {
+            if (cells_b != E.const_cells) { set_error("h2w_plan_equalities: internal: constant-equality cells depend on the proof"); rc = -1; }
+            std::map<uint64_t, int64_t> where;
+            for (size_t w = 0; w < wa.size(); w++) where[wa[w]] = (int64_t)w;
+            for (size_t i = 0; rc == 0 && i < E.const_cells.size(); i++) {
+                if (fr_eq(E.const_values[i], values_b[i])) continue;
+                auto it = where.find(E.const_values[i].l[0]);
+                if (it == where.end() || (E.const_values[i].l[1] | E.const_values[i].l[2] | E.const_values[i].l[3]) || values_b[i].l[0] != wb[(size_t)it->second]) {
+                    set_error("h2w_plan_equalities: internal: a proof-dependent constant is not a proof word"); rc = -1;
+                } else E.const_word[i] = it->second;
+            }
+        }
+    }
+    if (rc != 0) { E.pairs.clear(); E.const_cells.clear(); E.const_values.clear(); E.const_word.clear(); return -1; }
+    E.ready = true;
+    return 0;
+}
+uint64_t h2w_plan_num_equalities(h2w_plan *p) { return p && plan_equalities_build(p) == 0 ? plan_equalities(p).pairs.size() / 2 : 0; }
+uint64_t h2w_plan_num_const_equalities(h2w_plan *p) { return p && plan_equalities_build(p) == 0 ? plan_equalities(p).const_cells.size() : 0; }
+int h2w_plan_equalities(h2w_plan *p, uint64_t *pairs) {
+    if (!p || !pairs) { set_error("h2w_plan_equalities: null argument"); return -1; }
+    if (plan_equalities_build(p) != 0) return -1;
+    const PlanEqualities &E = plan_equalities(p);
+    memcpy(pairs, E.pairs.data(), E.pairs.size() * sizeof(uint64_t)); return 0;
+}
+int h2w_plan_const_equalities(h2w_plan *p, const uint64_t *proof_words, uint64_t *cells, h2w_fr_t *values) {
+    if (!p || !cells || !values) { set_error("h2w_plan_const_equalities: null argument"); return -1; }
+    if (plan_equalities_build(p) != 0) return -1;
+    const PlanEqualities &E = plan_equalities(p);
+    memcpy(cells, E.const_cells.data(), E.const_cells.size() * sizeof(uint64_t)); memcpy(values, E.const_values.data(), E.const_values.size() * sizeof(fr_t));
+    for (size_t i = 0; i < E.const_word.size(); i++) if (E.const_word[i] >= 0) {
+        if (!proof_words) { set_error("h2w_plan_const_equalities: with Goldilocks-Poseidon caps the hash wires are constants of the circuit (hash/poseidon/hash.rs:86-96): pass the proof"); return -1; }
+        values[i] = fr_from_u64(proof_words[E.const_word[i]]);
+    }
+    return 0;
 }
 
 }  // extern "C"

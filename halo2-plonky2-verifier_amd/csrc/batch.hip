@@ -161,6 +161,10 @@ __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long
 
 using namespace h2w;
 
+struct h2w_plan;
+namespace h2w {
+PlanEqualities &plan_equalities(h2w_plan *p);
+}
 struct h2w_plan {
     h2w_shape_t shape; int device;
     TemplateTable tt; DeviceTables dt; StrandTable st; FrParams P;
@@ -170,16 +174,23 @@ struct h2w_plan {
     h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
+    PlanEqualities eqs;
     fr_t *d_bn_tab = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64, N_EV = 8, N_SIDE = 16;
-    hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 2 glue (+ Goldilocks Merkle strands) done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call
+    hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 7 / 2 glue (+ Goldilocks Merkle strands) start / done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
     bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
 };
 
+namespace h2w {
+PlanEqualities &plan_equalities(h2w_plan *p) { return p->eqs; }
+const h2w_shape_t &plan_shape(const h2w_plan *p) { return p->shape; }
+const h2w_poseidon_consts_t &plan_consts(const h2w_plan *p) { return p->h_consts; }
+uint64_t plan_cells(const h2w_plan *p) { return p->ncells; }
+}
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 extern "C" {
@@ -416,6 +427,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     }
     // 3. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per (proof, query);
     //    Goldilocks-Poseidon Merkle strands (hash_mode 0): one cooperating wavefront per (proof, query, tree) - these do write records
+    H2W_HIP(hipEventRecord(ev[7], stream));
     if (!(dbg_skip & 2)) {
         launch_glue_strands(A, nlanes, stream);
         if (p->shape.hash_mode == 0) {
@@ -726,7 +738,7 @@ int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batch
     DeviceGuard dg(p->device);
     H2W_HIP(hipEventSynchronize(ev[6]));
     H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));   // prologue strands
-    H2W_HIP(hipEventElapsedTime(&ms[1], ev[1], ev[2]));   // query glue strands (+ Goldilocks-Poseidon Merkle strands)
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[7], ev[2]));   // query glue strands (+ Goldilocks-Poseidon Merkle strands)
     H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[5]));   // PoseidonBN254 Merkle chain kernel (on its side stream; 0 for Goldilocks-Poseidon Merkle)
     H2W_HIP(hipEventElapsedTime(&ms[3], ev[2], ev[3]));   // expansion kernel
     H2W_HIP(hipEventElapsedTime(&ms[4], ev[0], ev[6]));   // whole call

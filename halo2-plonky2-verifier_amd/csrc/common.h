@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 #include "records.h"
 
 namespace h2w {
@@ -28,6 +29,17 @@ inline int device_of(const void *ptr) {
     if (!ptr || hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return a.type == hipMemoryTypeDevice ? a.device : -1;
 }
+
+// keygen lists of a plan's cell stream that need wires with cell identities (copy constraints, constant equalities): built once, on
+// demand, by abi_backend.cpp (the eager keygen context replays the shape) and cached in the plan
+struct PlanEqualities { bool ready = false; std::vector<uint64_t> pairs, const_cells; std::vector<fr_t> const_values; std::vector<int64_t> const_word; };   // const_word[i] >= 0: the constant IS that proof word
+}  // namespace h2w
+struct h2w_plan;
+namespace h2w {
+PlanEqualities &plan_equalities(h2w_plan *);                       // batch.hip
+const h2w_shape_t &plan_shape(const h2w_plan *);
+const h2w_poseidon_consts_t &plan_consts(const h2w_plan *);
+uint64_t plan_cells(const h2w_plan *);
 
 // arguments of the expansion kernel (expand.hip)
 struct ExpandArgs {

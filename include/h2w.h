@@ -198,11 +198,20 @@ uint64_t h2w_ctx_num_const_equalities(h2w_ctx *); int h2w_ctx_const_equalities(h
  * /root/reference; semantics [R]): Context::selector (one bit per cell: a vertical gate starts there),
  * the range-lookup registrations (RangeChip::range_check -> cells_to_lookup, in registration order), the FlexGate
  * break points (gates/flex_gate/threads: assign_with_constraints) and the column assignment of the witness
- * (assign_witnesses) incl. the lookup-advice columns.  Copy-constraint lists are NOT produced (next). */
+ * (assign_witnesses) incl. the lookup-advice columns, and the copy manager's lists (advice_equalities, constant_equalities). */
 uint64_t h2w_plan_num_gates(h2w_plan *);
 uint64_t h2w_plan_num_lookups(h2w_plan *);
 int h2w_plan_selectors(h2w_plan *, uint8_t *bitmap /* (num_cells + 7) / 8 bytes, bit i = cell i */);
 int h2w_plan_lookup_cells(h2w_plan *, uint64_t *cells /* num_lookups */);
+/* Copy constraints (pairs of cell offsets: Context::constrain_equal and the copies of Existing cells into gates, field/native.rs:185-193)
+ * and constant equalities (cell, constant) of the plan's cell stream - what the halo2-base Context the reference hands to MockProver
+ * carries (stark/mod.rs:483-518).  Built on first use by replaying the shape through an eager keygen context on the host. */
+uint64_t h2w_plan_num_equalities(h2w_plan *);
+uint64_t h2w_plan_num_const_equalities(h2w_plan *);
+int h2w_plan_equalities(h2w_plan *, uint64_t *pairs /* 2 per equality */);
+/* proof_words (host, h2w_plan_proof_words of them) may be NULL with PoseidonBN254 caps; with Goldilocks-Poseidon caps the reference loads
+ * every hash wire of the proof as a CONSTANT (hash/poseidon/hash.rs:86-96), so those constants are the proof's own words. */
+int h2w_plan_const_equalities(h2w_plan *, const uint64_t *proof_words, uint64_t *cells, h2w_fr_t *values);
 /* break_points[c] = last used row of column c (the cell there is repeated at row 0 of column c + 1); max_rows = 2^k - unusable_rows.
  * out may be NULL to query *n_out. */
 int h2w_break_points(const uint8_t *selectors, uint64_t n_cells, int k, int unusable_rows,
@@ -239,8 +248,8 @@ int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t
  * (= out[0] + out[1] + (num_queries - 1) * out[2]). */
 int h2w_plan_strand_layout(const h2w_plan *, uint64_t out[4]);
 /* The rest of the restated MockProver: copy constraints (bad[0] = pairs whose two cells differ) and constant equalities (bad[1])
- * over device advice streams.  The lists are static per shape: take them from an eager keygen context of the same shape
- * (h2w_ctx_equalities / h2w_ctx_const_equalities).  Synchronises the stream. */
+ * over device advice streams.  The lists are static per shape: h2w_plan_equalities / h2w_plan_const_equalities (or an eager keygen
+ * context of the same shape: h2w_ctx_equalities / h2w_ctx_const_equalities).  Synchronises the stream. */
 int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proof_stride_cells, uint64_t n_proofs,
                          const uint64_t *pairs, uint64_t n_pairs, const uint64_t *const_cells, const h2w_fr_t *const_values,
                          uint64_t n_const, uint64_t bad[2], void *stream);
@@ -251,7 +260,9 @@ int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proo
  * still produced — identical to the reference's arithmetic for Goldilocks words, unreduced for the hash).  The first
  * condition met wins. */
 int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream);
-/* 32-byte digest per proof (xor-rotate checksum of the cell stream), for streamed configs. */
+/* 32-byte checksum of n_cells cells (for streamed configurations, whose advice buffers are re-used before anything could read them
+ * back): digest[j] = sum over cells i of limb_j(cell i) * ((((i + 1) * 0x9E3779B97F4A7C15) | 1) + 2 j)  mod 2^64 - position-dependent,
+ * order-independent in its evaluation.  digest4_dev: 4 x u64, device.  One call per proof. */
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);
 /* Output format: the stream is canonical little-endian Fr (what Fr::from_repr / to_repr use).  For a consumer that copies cells into
  * halo2curves' in-memory representation (Montgomery form, R = 2^256) this converts n_cells cells in place on the device. */
@@ -272,6 +283,29 @@ uint64_t h2w_plan_num_record_cells(const h2w_plan *);
 /* Advice cells per proof of the MerkleTreeChip::verify_proof_to_cap_with_cap_index calls (merkle/mod.rs:57-78): with PoseidonBN254
  * caps these are the cells the chain kernel writes itself (its permutations' 4,032 cells each, the selects, the cap lookup). */
 uint64_t h2w_plan_num_chain_cells(const h2w_plan *);
+
+/* ------------------------------------------------------------------ 2c. batched chip ops on the device
+ * n independent instances of ONE GoldilocksChip / GoldilocksQuadExtChip operation, each in a fresh Context: the operands are loaded
+ * as witnesses (GoldilocksChip::load_witness, 28 cells each at lookup_bits 21; extension elements as two), then the op - the shape
+ * of the reference's chip tests (field/goldilocks/base.rs:476-495, extension.rs:473-493).  One lane per instance computes the
+ * values, the expansion kernel writes advice_dev[n][num_cells].  status_dev[i] = 0, or 1 / 2 where the reference panics
+ * (GoldilocksChip::div by zero, base.rs:379; extension inverse of zero, extension.rs:327: the cells are then those of the op on
+ * the substituted operand 1, as in the batched verifier path).  operands_dev: [n][num_operands] canonical Goldilocks words. */
+#define H2W_OP_GL_ADD 0      /* a, b       base.rs:251-260 */
+#define H2W_OP_GL_SUB 1      /* a, b       base.rs:274-283 */
+#define H2W_OP_GL_MUL 2      /* a, b       base.rs:296-305 */
+#define H2W_OP_GL_MUL_ADD 3  /* a, b, c    base.rs:319-329 */
+#define H2W_OP_GL_DIV 4      /* a, b       base.rs:371-393 */
+#define H2W_OP_GL_INV 5      /* a          base.rs:395-399 */
+#define H2W_OP_EXT_MUL 6     /* a0 a1 b0 b1  extension.rs:211-234 */
+#define H2W_OP_EXT_INV 7     /* a0 a1        extension.rs:320-340 */
+#define H2W_OP_EXT_DIV 8     /* a0 a1 b0 b1  extension.rs:237-246 */
+typedef struct h2w_chipbatch h2w_chipbatch;
+h2w_chipbatch *h2w_chipbatch_new(int op, int lookup_bits, int device_id);
+void           h2w_chipbatch_free(h2w_chipbatch *);
+uint64_t       h2w_chipbatch_num_operands(const h2w_chipbatch *);   /* u64 words per instance */
+uint64_t       h2w_chipbatch_num_cells(const h2w_chipbatch *);      /* advice cells per instance */
+int            h2w_chipbatch_run(h2w_chipbatch *, const uint64_t *operands_dev, uint64_t n, void *advice_dev, uint32_t *status_dev, void *stream);
 
 /* ------------------------------------------------------------------ the step BEFORE the path
  * Synthetic VALID FRI instances generated on the GPU (SURVEY 8(d) variant (A)): low-degree extension (Goldilocks NTT on the coset

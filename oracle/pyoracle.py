@@ -186,6 +186,12 @@ class Ctx:
         n = self.num_cells()
         return C.string_at(self.L.orc_advice(self.p), n * 32)
 
+    def advice_array(self):
+        """The advice as an (n, 4) uint64 numpy view of the context's own memory (no copy; valid until the context changes)."""
+        import numpy as np
+        n = self.num_cells()
+        return np.ctypeslib.as_array(C.cast(self.L.orc_advice(self.p), C.POINTER(C.c_uint64)), shape=(n, 4))
+
     def error(self):
         return self.L.orc_error(self.p).decode()
 

@@ -313,3 +313,47 @@ def test_expand_records_alone_rewrites_the_same_cells(h2w, h2w_api, oracle, cons
     assert int(wiped.sum()) == 2 * (plan.num_cells - plan.num_record_cells)
     assert (again[~wiped] == full[~wiped]).all()
     plan.close()
+
+
+def test_two_plans_with_different_tables_interleaved_on_two_streams(h2w, h2w_api, oracle, consts, published):
+    """Distinct handles are independent (include/h2w.h): two PoseidonBN254 plans of the same shape with DIFFERENT Poseidon tables (the
+    seeded synthetic set and the published one) run concurrently, interleaved over two streams, each launch into its own buffers;
+    every launch's stream equals the oracle's for its own tables.  (The tables are per-plan device buffers staged into LDS by the chain
+    kernel; round 1 kept them in one process-wide __constant__ symbol, which two such plans would have raced on.)"""
+    import torch
+    (ko_a, kh_a), (ko_b, kh_b) = consts, published
+    sh = h2w.fibonacci_shape(8, 3, rate_bits=1, hash_mode=1, cap_height=2); osh = oracle.fibonacci_shape(8, 3, rate_bits=1, hash_mode=1, cap_height=2)
+    plans = [h2w_api.Plan(sh, kh_a), h2w_api.Plan(sh, kh_b)]
+    kos = [ko_a, ko_b]
+    n, rounds = 2, 3
+    proofs = [oracle.synth_proof(osh, 500 + i) for i in range(n)]
+    host = torch.empty(n * plans[0].proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * plans[0].proof_words:(i + 1) * plans[0].proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for k in (0, 1):
+            advice = torch.zeros(n * plans[k].num_cells * 32, dtype=torch.uint8, device="cuda")
+            ws = torch.zeros(plans[k].workspace_bytes(n), dtype=torch.uint8, device="cuda")
+            outs.append((k, advice, ws))
+    torch.cuda.synchronize()
+    for j, (k, advice, ws) in enumerate(outs):                       # all launches enqueued before anything is waited for
+        plans[k].run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), streams[(j + k) % 2].cuda_stream)
+    torch.cuda.synchronize()
+    want = []
+    for k in (0, 1):
+        w = b""
+        for p in proofs:
+            ctx = oracle.Ctx(21)
+            assert oracle.verify_stark(ctx, osh, kos[k], p) == 0
+            w += ctx.advice_bytes(); ctx.close()
+        want.append(w)
+    assert want[0] != want[1]
+    for k, advice, ws in outs:
+        assert plans[k].status(ws.data_ptr(), n) == [0] * n
+        assert advice.cpu().numpy().tobytes() == want[k]
+    for pl in plans:
+        pl.close()

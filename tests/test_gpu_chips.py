@@ -157,3 +157,59 @@ def test_permutations_reproduce_published_known_answers(h2w, h2w_api, oracle, pu
         pr.OL.orc_bn_poseidon_permute(pr.op, C.byref(ko), pr.oarr([x[1] for x in st]), oo)
         assert [hex(g.int_value()) for g in go] == v["out"]
     pr.check()
+
+
+OPS = {"add": 0, "sub": 1, "mul": 2, "mul_add": 3, "div": 4, "inv": 5, "ext_mul": 6, "ext_inv": 7, "ext_div": 8}
+
+
+@pytest.mark.parametrize("op", sorted(OPS))
+@pytest.mark.parametrize("lookup_bits", [21, 13])
+def test_batched_chip_ops_and_device_status_words(h2w, oracle, op, lookup_bits):
+    """h2w_chipbatch_*: n independent instances of one GoldilocksChip / QuadExtChip op on the device (operands loaded as witnesses, then the
+    op: the reference's test_mul shape, base.rs:476-495), every instance's cells equal to the oracle's.  Where the reference PANICS -
+    GoldilocksChip::div by zero (base.rs:379), extension inverse of zero (extension.rs:327) - the device status word of that instance is
+    1 / 2, the oracle's context reports the failed assertion, and both sides emit the cells of the substituted operand."""
+    import numpy as np
+    import torch
+    L = h2w.lib(); OL = oracle.lib()
+    h = L.h2w_chipbatch_new(OPS[op], lookup_bits, 0)
+    assert h, h2w.last_error()
+    nw, nc = int(L.h2w_chipbatch_num_operands(h)), int(L.h2w_chipbatch_num_cells(h))
+    rnd = random.Random(sum(map(ord, op)))
+    n = 200
+    ops = [[rnd.randrange(P) for _ in range(nw)] for _ in range(n)]
+    ops[0] = [0] * nw; ops[1] = [P - 1] * nw; ops[2] = [1] * nw                      # edges; all-zero operands hit the panics of div / inv
+    if op in ("div", "ext_div"):
+        ops[3] = [rnd.randrange(1, P) for _ in range(nw // 2)] + [0] * (nw // 2)      # non-zero numerator over a zero denominator
+    d_ops = torch.tensor(np.array(ops, dtype=np.uint64).view(np.int64).reshape(-1), dtype=torch.int64, device="cuda")
+    advice = torch.zeros(n * nc * 32, dtype=torch.uint8, device="cuda")
+    status = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    assert L.h2w_chipbatch_run(h, d_ops.data_ptr(), n, advice.data_ptr(), status.data_ptr(), 0) == 0, h2w.last_error()
+    torch.cuda.synchronize()
+    got = advice.cpu().numpy().tobytes(); st = status.cpu().tolist()
+    for i, w in enumerate(ops):
+        ctx = oracle.Ctx(lookup_bits)
+        av = [OL.orc_gl_load_witness(ctx.p, x) for x in w]
+        if op in ("add", "sub", "mul", "div"):
+            getattr(OL, "orc_gl_" + op)(ctx.p, av[0], av[1])
+        elif op == "mul_add":
+            OL.orc_gl_mul_add(ctx.p, av[0], av[1], av[2])
+        elif op == "inv":
+            OL.orc_gl_inv(ctx.p, av[0])
+        else:
+            a = (oracle.AV * 2)(av[0], av[1]); out = (oracle.AV * 2)()
+            if op == "ext_inv":
+                OL.orc_ext_inv(ctx.p, a, out)
+            else:
+                b = (oracle.AV * 2)(av[2], av[3])
+                (OL.orc_ext_mul if op == "ext_mul" else OL.orc_ext_div)(ctx.p, a, b, out)
+        assert ctx.num_cells() == nc
+        assert got[i * nc * 32:(i + 1) * nc * 32] == ctx.advice_bytes(), (op, i)
+        panics = bool(ctx.error())
+        zero_gl = (op == "div" and w[1] == 0) or (op == "inv" and w[0] == 0)
+        zero_ext = (op == "ext_inv" and w[0] == 0 and w[1] == 0) or (op == "ext_div" and w[2] == 0 and w[3] == 0)
+        assert panics == (zero_gl or zero_ext), (op, i, ctx.error())
+        assert st[i] == (1 if zero_gl else 2 if zero_ext else 0), (op, i, st[i])
+        ctx.close()
+    assert any(st) == (op in ("div", "inv", "ext_inv", "ext_div"))
+    L.h2w_chipbatch_free(h)

@@ -198,6 +198,86 @@ def test_config4_pipeline_on_the_device(h2w, h2w_api, oracle, published):
     plan.close()
 
 
+def test_config4_full_size_streamed_with_digests(h2w, h2w_api, oracle, published):
+    """BASELINE.json configs[3] at FULL size on one GPU: 256 independent 2^16-row proofs (28 queries, rate_bits 2, PoseidonBN254 caps),
+    8 steps of 32: prover -> witness -> every gate and lookup checked on the device -> one h2w_advice_digest per proof, the advice
+    buffer re-used by the next step (the 256 streams together are 191 GB).  Four sampled proofs' digests equal the checksum of the
+    oracle's stream of the same proof, two of those streams are compared byte for byte, and all 256 digests are distinct."""
+    import numpy as np
+    import torch
+    ko, kh = published
+    steps, per = 8, 32
+    sh = h2w.fibonacci_shape(16, 28, rate_bits=2, hash_mode=1); osh = oracle.fibonacci_shape(16, 28, rate_bits=2, hash_mode=1)
+    pr = h2w_api.Prover(sh, kh); plan = h2w_api.Plan(sh, kh)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda"); g.manual_seed(4040)
+    proofs = torch.zeros(per * pr.proof_words, dtype=torch.int64, device="cuda")
+    advice = torch.zeros(per * plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(per), dtype=torch.uint8, device="cuda")
+    digests = torch.zeros(steps * per * 4, dtype=torch.int64, device="cuda")
+    sampled = {(0, 0): True, (3, 17): False, (5, 9): False, (7, 31): True}        # (step, proof) -> compare every byte too
+    for step in range(steps):
+        coefs = torch.randint(0, 1 << 62, (per * pr.num_polys << 16,), dtype=torch.int64, device="cuda", generator=g)
+        pr.prove_batch(coefs.data_ptr(), [step, 8, 9] * per, proofs.data_ptr(), per, st)
+        plan.run(proofs.data_ptr(), per, advice.data_ptr(), ws.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert plan.status(ws.data_ptr(), per) == [0] * per
+        assert plan.check_constraints(advice.data_ptr(), per) == (0, 0)
+        for i in range(per):
+            plan.advice_digest(advice.data_ptr() + i * plan.num_cells * 32, plan.num_cells, digests.data_ptr() + (step * per + i) * 32, st)
+        torch.cuda.synchronize()
+        for (s_, i), every_byte in sampled.items():
+            if s_ != step:
+                continue
+            words = proofs[i * plan.proof_words:(i + 1) * plan.proof_words].cpu().numpy().tobytes()
+            ctx = oracle.Ctx(21); ctx.reserve(plan.num_cells)
+            assert oracle.verify_stark(ctx, osh, ko, (C.c_uint64 * plan.proof_words).from_buffer_copy(words)) == 0
+            want = ctx.advice_bytes(); ctx.close()
+            got = [int(x) & 0xFFFFFFFFFFFFFFFF for x in digests[(step * per + i) * 4:(step * per + i + 1) * 4].cpu().tolist()]
+            assert got == h2w_api.advice_digest_reference(want), (step, i)
+            if every_byte:
+                assert advice[i * plan.num_cells * 32:(i + 1) * plan.num_cells * 32].cpu().numpy().tobytes() == want
+    d = digests.cpu().numpy().reshape(steps * per, 4)
+    assert len({row.tobytes() for row in d}) == steps * per                       # 256 independent streams
+    pr.close(); plan.close()
+
+
+def test_streamed_goldilocks_caps_digest(h2w, h2w_api, oracle, published):
+    """The streamed form of configs[3] with Goldilocks-Poseidon caps (87.8 G cells for the 256 proofs: SURVEY 7 "must stream with an
+    on-device digest"): 343 M-cell streams generated into ONE re-used buffer, checked on the device and digested; the digest of one
+    stream equals the checksum of the oracle's stream of the same proof (11 GB on the host), and the streams differ."""
+    import torch
+    ko, kh = published
+    sh = h2w.fibonacci_shape(16, 28, rate_bits=2, hash_mode=0); osh = oracle.fibonacci_shape(16, 28, rate_bits=2, hash_mode=0)
+    pr = h2w_api.Prover(sh, kh); plan = h2w_api.Plan(sh, kh)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda"); g.manual_seed(4041)
+    n = 3
+    proof = torch.zeros(pr.proof_words, dtype=torch.int64, device="cuda")
+    advice = torch.zeros(plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(1), dtype=torch.uint8, device="cuda")
+    digests = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+    keep = None
+    for i in range(n):
+        coefs = torch.randint(0, 1 << 62, (pr.num_polys << 16,), dtype=torch.int64, device="cuda", generator=g)
+        pr.prove_batch(coefs.data_ptr(), [i, 2, 3], proof.data_ptr(), 1, st)
+        plan.run(proof.data_ptr(), 1, advice.data_ptr(), ws.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert plan.status(ws.data_ptr(), 1) == [0]
+        assert plan.check_constraints(advice.data_ptr(), 1) == (0, 0)
+        plan.advice_digest(advice.data_ptr(), plan.num_cells, digests.data_ptr() + i * 32, st)
+        if i == 1:
+            keep = proof.cpu().numpy().tobytes()
+    torch.cuda.synchronize()
+    got = [[int(x) & 0xFFFFFFFFFFFFFFFF for x in digests[4 * i:4 * i + 4].cpu().tolist()] for i in range(n)]
+    assert len({tuple(x) for x in got}) == n
+    ctx = oracle.Ctx(21); ctx.reserve(plan.num_cells)
+    assert oracle.verify_stark(ctx, osh, ko, (C.c_uint64 * plan.proof_words).from_buffer_copy(keep)) == 0
+    assert ctx.num_cells() == plan.num_cells
+    assert got[1] == h2w_api.advice_digest_reference(ctx.advice_array())
+    ctx.close(); pr.close(); plan.close()
+
+
 def test_config5_valid_proof(h2w, h2w_api, oracle, published):
     """BASELINE.json configs[4]: 2^20 rows, 84 queries, PoseidonBN254 caps of height 4: a GPU-generated valid instance, its
     59.7 M + load cells checked gate by gate on the device and compared with the oracle's stream."""

@@ -94,3 +94,25 @@ def test_full_verifier_through_the_eager_boundary(h2w, h2w_api, oracle, consts, 
     assert oracle.verify_stark(octx, osh, ko, proof) == 0
     compare(ctx, octx)
     ctx.close(); octx.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_plan_exports_the_static_equality_lists(h2w, h2w_api, oracle, consts, mode):
+    """h2w_plan_equalities / h2w_plan_const_equalities (the batched path's copy manager): the lists a plan hands out -
+    built by a host replay, no device - equal the oracle's keygen bookkeeping for an ARBITRARY proof of the shape: the copy constraints
+    and the constant-equality cells are static, and so are the constants, except that with Goldilocks-Poseidon caps the reference loads
+    the proof's hash wires as constants (hash/poseidon/hash.rs:86-96) - those are filled in from the proof passed in."""
+    ko, kh = consts
+    sh = h2w.fibonacci_shape(6, 2, hash_mode=mode, cap_height=2); osh = oracle.fibonacci_shape(6, 2, hash_mode=mode, cap_height=2)
+    plan = h2w_api.Plan(sh, kh)
+    proof = oracle.prove_fri(osh, ko, 77)
+    octx = oracle.Ctx(21, witness_gen_only=False)
+    assert oracle.verify_stark(octx, osh, ko, proof) == 0
+    assert norm_eq(plan.equalities()) == norm_eq(octx.equalities())
+    assert sorted(plan.const_equalities(proof)) == sorted(octx.const_equalities())
+    if mode == 1:
+        assert sorted(plan.const_equalities()) == sorted(octx.const_equalities())        # nothing depends on the proof
+    else:
+        with pytest.raises(h2w_api.H2WError):
+            plan.const_equalities()
+    octx.close(); plan.close()

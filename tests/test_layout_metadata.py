@@ -196,20 +196,21 @@ def test_full_size_streams_satisfy_all_gates_and_lookups(h2w, h2w_api, oracle, c
 @pytest.mark.parametrize("mode", [1, 0])
 def test_full_mockprover_on_the_device(h2w, h2w_api, oracle, consts, mode):
     """The restated MockProver entirely on the GPU-generated stream: gates and lookups (plan metadata) plus the copy constraints and
-    constant equalities recorded by an eager keygen context of the same shape.  On a VALID FRI instance every constraint holds,
+    constant equalities the plan exports (equal to what an eager keygen context of the same shape records).  On a VALID FRI instance every constraint holds,
     chip-level assert_equal included; on a corrupted proof only copy constraints break."""
     import ctypes as C
     import torch
     ko, kh = consts
     sh, osh = _shapes(h2w, oracle, mode, 21, dict(d=6, q=2, cap=2))
     good = oracle.prove_fri(osh, ko, 2024)
-    # keygen: one eager run of the shape.  Gates, copy constraints and lookups are static per shape; so are the constant equalities
-    # except for the reference's quirk that Goldilocks-Poseidon hash wires are loaded as CONSTANTS (hash/poseidon/hash.rs:86-96),
-    # which ties those to the proof: the keygen run uses the same proof.
-    kctx = h2w_api.Context(21, witness_gen_only=False)
-    assert h2w.lib().h2w_chip_verify_stark(kctx.p, C.byref(sh), C.byref(kh), good) == 0, h2w.last_error()
-    eqs, ceqs = kctx.equalities(), kctx.const_equalities()
+    # keygen: the plan's own lists (h2w_plan_equalities / _const_equalities: a host replay of the shape).  Gates, copy constraints and
+    # lookups are static per shape; so are the constant equalities except for the reference's quirk that Goldilocks-Poseidon hash wires
+    # are loaded as CONSTANTS (hash/poseidon/hash.rs:86-96), which ties those to the proof: they are filled in from `good`.
     plan = h2w_api.Plan(sh, kh)
+    eqs, ceqs = plan.equalities(), plan.const_equalities(good)
+    kctx = h2w_api.Context(21, witness_gen_only=False)          # ... and they are what an eager keygen context of the same proof records
+    assert h2w.lib().h2w_chip_verify_stark(kctx.p, C.byref(sh), C.byref(kh), good) == 0, h2w.last_error()
+    assert sorted(eqs) == sorted(kctx.equalities()) and sorted(ceqs) == sorted(kctx.const_equalities())
     assert kctx.num_cells() == plan.num_cells and kctx.gate_cells() == [i for i in np.nonzero(np.unpackbits(np.frombuffer(plan.selectors(), dtype=np.uint8), bitorder="little"))[0]]
     bad_proof = (C.c_uint64 * len(good))(*good); bad_proof[len(good) // 2] ^= 1
     st = torch.cuda.current_stream().cuda_stream
