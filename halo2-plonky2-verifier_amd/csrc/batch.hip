@@ -87,6 +87,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_coop(Batch
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
     CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm; sink.cc.init(A.cm);
+    sink.bind_lds();
     sink.emit = own_prologue(A, p);      // every rank of a sharded run needs the challenges; the proof's owner emits the prologue block
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
@@ -106,6 +107,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_coop(Batc
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
+    sink.bind_lds();
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     const uint64_t x = A.cbs[p].fri_query_indices[q];

@@ -26,6 +26,12 @@ __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)
 // Goldilocks-Poseidon round constants + MDS, staged in LDS by the cooperative kernels (stage_glp_consts) and read with
 // ds_read (a namespace-scope __shared__ array keeps the LDS address space; a pointer member would decay to flat).
 __shared__ uint64_t s_glp_k[GLP_CONST_WORDS];
+__shared__ uint64_t s_glp_a[SPONGE_WIDTH], s_glp_b[SPONGE_WIDTH];      // the permutation's state exchange buffers
+// LDS pointers are handed to the (out-of-line) permutation through the sink: a __shared__ array that several kernels use is reached
+// from a non-kernel function through llvm.amdgcn.lds.offset.table - a GLOBAL load of the offset at every use, i.e. a vmcnt(0) wait
+// for every record store in flight, inside the round loops (that was 60 of the 89 us of a permutation).  A kernel knows the
+// addresses at compile time and passes them down.
+typedef __attribute__((address_space(3))) uint64_t lds64_t;
 constexpr int KO_ARC = 0, KO_CIRC = 360, KO_DIAG = 372, KO_FIRST = 384, KO_PRC = 396, KO_INIT = 418, KO_WHAT = 539, KO_VS = 781;
 static_assert(KO_VS + 242 == GLP_CONST_WORDS, "Goldilocks constant block layout");
 __device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k, int tid, int nthreads) {
@@ -44,6 +50,8 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) { return __shfl
 template <bool COLS> struct CoopSinkT {
     static constexpr bool kCoop = true, kSplitOnly = false;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; int dbg_skip_perm = 0; ColPolicy<COLS> cc;
+    lds64_t *lk = nullptr, *la = nullptr, *lb = nullptr;      // s_glp_k, s_glp_a, s_glp_b of the running kernel (set by bind_lds)
+    __device__ __forceinline__ void bind_lds() { lk = (lds64_t *)s_glp_k; la = (lds64_t *)s_glp_a; lb = (lds64_t *)s_glp_b; }
     bool emit = true;            // false: values only (a sharded run computes every prologue for its challenges, but only the owning rank emits it)
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (lane == 0 && emit) g_store_rec(recs + nrec, a, b, c, d);
@@ -86,7 +94,7 @@ template <bool COLS> struct CoopSinkT {
     }
 
     __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
-        __shared__ uint64_t s_a[SPONGE_WIDTH], s_b[SPONGE_WIDTH];
+        lds64_t *const K = lk, *const s_a = la, *const s_b = lb;      // (by value: one read of the sink object per call)
         rec_t *R = recs + nrec;
         if (dbg_skip_perm) {   // timing-only diagnostic (H2W_DBG_SKIP_PERM=1): advance the counters, skip the arithmetic
             const uint64_t nG0 = ncells[T_GLOP], nKA0 = ncells[T_KA_GLOP];
@@ -101,7 +109,7 @@ template <bool COLS> struct CoopSinkT {
         int base = 0, round_ctr = 0;
         auto full_round = [&]() {
             if (l < SPONGE_WIDTH) {
-                uint64_t x = s_a[l]; const uint64_t rc = s_glp_k[KO_ARC + l + SPONGE_WIDTH * round_ctr];
+                uint64_t x = s_a[l]; const uint64_t rc = K[KO_ARC + l + SPONGE_WIDTH * round_ctr];
                 W(base + l, rc, 1, x); x = gl_add(x, rc);                                   // constant_layer
                 const int sb = base + 12 + 4 * l;                                            // sbox_monomial: x^7
                 const uint64_t x2 = gl_mul(x, x); W(sb, x, x, 0);
@@ -121,8 +129,8 @@ template <bool COLS> struct CoopSinkT {
                 const int rr = pass * 4 + grp13;
                 uint64_t c = 0, v = 0, x = 0;
                 if (l < 52) {
-                    if (idx13 < 12) { c = s_glp_k[KO_CIRC + idx13]; int vi = idx13 + rr; if (vi >= 12) vi -= 12; v = s_b[vi]; }
-                    else { c = s_glp_k[KO_DIAG + rr]; v = s_b[rr]; }
+                    if (idx13 < 12) { c = K[KO_CIRC + idx13]; int vi = idx13 + rr; if (vi >= 12) vi -= 12; v = s_b[vi]; }
+                    else { c = K[KO_DIAG + rr]; v = s_b[rr]; }
                     x = gl_mul(c, v);
                 }
 #pragma unroll
@@ -142,7 +150,7 @@ template <bool COLS> struct CoopSinkT {
         for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round();
         // ---- partial rounds (hash/poseidon/permutation.rs:216-239)
         if (l < SPONGE_WIDTH) {                                                              // partial_first_constant_layer
-            const uint64_t x = s_a[l], c = s_glp_k[KO_FIRST + l];
+            const uint64_t x = s_a[l], c = K[KO_FIRST + l];
             W(base + l, c, 1, x); s_b[l] = gl_add(x, c);
         }
         wave_sync();
@@ -151,7 +159,7 @@ template <bool COLS> struct CoopSinkT {
         else if (l < SPONGE_WIDTH) {
             uint64_t res = 0;
             for (int r = 1; r < SPONGE_WIDTH; r++) {
-                const uint64_t t = s_glp_k[KO_INIT + (r - 1) * 11 + (l - 1)], v = s_b[r];
+                const uint64_t t = K[KO_INIT + (r - 1) * 11 + (l - 1)], v = s_b[r];
                 W(base + 1 + (r - 1) * 11 + (l - 1), t, v, res); res = gl_muladd(t, v, res);
             }
             s_a[l] = res;
@@ -165,15 +173,15 @@ template <bool COLS> struct CoopSinkT {
                 const uint64_t x4 = gl_mul(x2, x2); W(base + 1, x2, x2, 0);
                 const uint64_t x6 = gl_mul(x4, x2); W(base + 2, x4, x2, 0);
                 const uint64_t x7 = gl_mul(x6, x); W(base + 3, x6, x, 0);
-                const uint64_t c = s_glp_k[KO_PRC + r];
+                const uint64_t c = K[KO_PRC + r];
                 W(base + 4, c, 1, x7); s_a[0] = gl_add(x7, c);
             }
             wave_sync();
             const uint64_t s0 = s_a[0];                                                      // mds_partial_layer_fast
             {   // d = m00*s0 + sum_i w_hat_i * st_i as an inclusive scan over lanes 0..11 (records need every partial sum)
                 uint64_t t = 0, v = 0, x = 0;
-                if (l == 0) { t = s_glp_k[KO_CIRC] + s_glp_k[KO_DIAG]; v = s0; }
-                else if (l < SPONGE_WIDTH) { t = s_glp_k[KO_WHAT + r * 11 + (l - 1)]; v = s_a[l]; }
+                if (l == 0) { t = K[KO_CIRC] + K[KO_DIAG]; v = s0; }
+                else if (l < SPONGE_WIDTH) { t = K[KO_WHAT + r * 11 + (l - 1)]; v = s_a[l]; }
                 if (l < SPONGE_WIDTH) x = gl_mul(t, v);
 #pragma unroll
                 for (int d = 1; d < 16; d <<= 1) { const uint64_t y = shfl_up64(x, d); if (l >= d) x = gl_add_c(x, y); }
@@ -182,7 +190,7 @@ template <bool COLS> struct CoopSinkT {
                 if (l == 0) W(base + 17, 0, 0, 0);
                 if (l == SPONGE_WIDTH - 1) s_b[0] = x;
                 if (l > 0 && l < SPONGE_WIDTH) {
-                    const uint64_t tv = s_glp_k[KO_VS + r * 11 + (l - 1)];
+                    const uint64_t tv = K[KO_VS + r * 11 + (l - 1)];
                     W(base + 17 + l, tv, s0, v); s_b[l] = gl_muladd(tv, s0, v);
                 }
             }
