@@ -236,7 +236,7 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
     typedef FastMap<L> M;
     constexpr int NCH = (M::VT + FAST_CH - 1) / FAST_CH;
     constexpr int ROW = NCH * FAST_CH * 16 + 16;              // bytes per record row of the LDS tile: the low halves of its virtual cells (+ padding)
-    constexpr int TILE = FAST_T * ROW + 64;                   // + a 32-byte block: zeros and the high half of -2^RB (what the odd pieces store)
+    constexpr int TILE = (FAST_T + 1) * ROW;                  // + one row of HIGH halves: zeros, and the high half of -2^RB at its two cells (what the odd pieces store)
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[EXPAND_THREADS / 64][TILE];
     __shared__ uint2 s_vbr[EXPAND_THREADS / 64][FAST_T];     // per record: {flat index of its virtual cell 0, vs | ve << 8}
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -250,9 +250,10 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
     // flush roles: lane -> 16-byte piece (lane % 16) of a 256-byte step of record lane / 16 of a group of four records
     const int piece = lane & 15, kc = piece >> 1; const bool hi = piece & 1;
     const unsigned char *rd_base = &s_tile[wv][(lane >> 4) * ROW + kc * 16];
-    const unsigned char *z_ptr = &s_tile[wv][FAST_T * ROW], *n_ptr = z_ptr + 16;
+    const unsigned char *hi_base = &s_tile[wv][FAST_T * ROW + kc * 16];
     unsigned char *const out_half = outb + (hi ? 16 : 0);
-    if (lane == 0) { *reinterpret_cast<u128s *>(&s_tile[wv][FAST_T * ROW]) = u128s{0, 0}; *reinterpret_cast<u128s *>(&s_tile[wv][FAST_T * ROW + 16]) = u128s{neg2, neg3}; }
+    for (int v = lane; v < NCH * FAST_CH; v += 64)
+        *reinterpret_cast<u128s *>(&s_tile[wv][FAST_T * ROW + v * 16]) = fast_is_neg<L>(v) ? u128s{neg2, neg3} : u128s{0, 0};
 
     uint32_t tile;
     { uint32_t t0 = 0; if (lane == 0) t0 = atomicAdd(&A.tile_ctr[proof], 1u); tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0); }
@@ -319,18 +320,20 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
 #pragma unroll 1
             for (int g = 0; g < FAST_T / 4; g++) {
                 const uint2 br = s_vbr[wv][g * 4 + (lane >> 4)];
-                const uint32_t vs_ = br.y & 255u, len_ = (br.y >> 8) - vs_;
-                const unsigned char *rd_g = rd_base + g * 4 * ROW;
+                const int vs_ = (int)(br.y & 255u), ve_ = (int)(br.y >> 8);
+                // steps in which this lane's cell 8 c + kc is one of the record's: c in [c_lo, c_hi]
+                const int c_lo = (vs_ - kc + 7) >> 3, c_hi = ve_ - 1 - kc >= 0 ? (ve_ - 1 - kc) >> 3 : -1;
+                const unsigned char *rd = hi ? hi_base : rd_base + g * 4 * ROW;                   // low halves from the record's row, high halves from the template row
+                unsigned char *const dst = out_half + ((ull)br.x + (ull)(uint32_t)kc) * 32;       // + 256 c per step: an immediate offset
+                if (__all(c_lo <= 1 && c_hi >= NCH - 2)) {       // four whole Goldilocks-op blocks (the usual case): only the first and the last step are ragged
+                    if (c_lo <= 0) *reinterpret_cast<u128s *>(dst) = *reinterpret_cast<const u128s *>(rd);
 #pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    int negk = -1;
+                    for (int c = 1; c < NCH - 1; c++) *reinterpret_cast<u128s *>(dst + c * FAST_CH * 32) = *reinterpret_cast<const u128s *>(rd + c * FAST_CH * 16);
+                    if (c_hi >= NCH - 1) *reinterpret_cast<u128s *>(dst + (NCH - 1) * FAST_CH * 32) = *reinterpret_cast<const u128s *>(rd + (NCH - 1) * FAST_CH * 16);
+                } else {
 #pragma unroll
-                    for (int k = 0; k < FAST_CH; k++) if (fast_is_neg<L>(FAST_CH * c + k)) negk = k;
-                    const unsigned char *hi_ptr = (negk >= 0 && kc == negk) ? n_ptr : z_ptr;      // what this lane's odd piece holds in this step
-                    const unsigned char *a = hi ? hi_ptr : rd_g + c * FAST_CH * 16;
-                    const u128s v = *reinterpret_cast<const u128s *>(a);
-                    const uint32_t vcell = (uint32_t)(FAST_CH * c) + (uint32_t)kc;
-                    if (vcell - vs_ < len_) *reinterpret_cast<u128s *>(out_half + (ull)(br.x + vcell) * 32) = v;
+                    for (int c = 0; c < NCH; c++)
+                        if (c >= c_lo && c <= c_hi) *reinterpret_cast<u128s *>(dst + c * FAST_CH * 32) = *reinterpret_cast<const u128s *>(rd + c * FAST_CH * 16);
                 }
             }
             if (__any(slow)) {
