@@ -235,7 +235,7 @@ constexpr int FAST_T = 16;                                  // records per pass 
 template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
     typedef FastMap<L> M;
     constexpr int NCH = (M::VT + FAST_CH - 1) / FAST_CH;
-    constexpr int ROW = NCH * FAST_CH * 16 + 16;              // bytes per record row of the LDS tile: the low halves of its virtual cells (+ padding)
+    constexpr int ROW = M::VT * 16 + 16;                      // bytes per record row of the LDS tile: the low halves of its virtual cells (+ padding); the last step's lanes past VT never read
     constexpr int TILE = (FAST_T + 1) * ROW;                  // + one row of HIGH halves: zeros, and the high half of -2^RB at its two cells (what the odd pieces store)
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[EXPAND_THREADS / 64][TILE];
     __shared__ uint2 s_vbr[EXPAND_THREADS / 64][FAST_T];     // per record: {flat index of its virtual cell 0, vs | ve << 8}
@@ -252,7 +252,7 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
     const unsigned char *rd_base = &s_tile[wv][(lane >> 4) * ROW + kc * 16];
     const unsigned char *hi_base = &s_tile[wv][FAST_T * ROW + kc * 16];
     unsigned char *const out_half = outb + (hi ? 16 : 0);
-    for (int v = lane; v < NCH * FAST_CH; v += 64)
+    for (int v = lane; v < M::VT; v += 64)
         *reinterpret_cast<u128s *>(&s_tile[wv][FAST_T * ROW + v * 16]) = fast_is_neg<L>(v) ? u128s{neg2, neg3} : u128s{0, 0};
 
     uint32_t tile;
@@ -310,6 +310,7 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
                 for (int c = 0; c < NCH; c++) {
 #pragma clang loop unroll(full)
                     for (int k = 0; k < FAST_CH; k++) {
+                        if (FAST_CH * c + k >= M::VT) continue;
                         const lohi_t x = fast_vcell<L>(FAST_CH * c + k, b, neg0, neg1);
                         *reinterpret_cast<u128s *>(my_row + (FAST_CH * c + k) * 16) = u128s{x.lo, x.hi};
                     }
