@@ -402,7 +402,10 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     hipStream_t cstream = stream;      // chain kernel's stream
     if (p->fork_chains && p->shape.hash_mode == 1) {
         int k = 0; while (k < p->n_side && p->side_of[k] != stream) k++;
-        if (k == p->n_side && p->n_side < h2w_plan::N_SIDE) { H2W_HIP(hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking)); p->side_of[k] = stream; p->n_side++; }
+        if (k == p->n_side && p->n_side < h2w_plan::N_SIDE) {
+            int lo_pri = 0, hi_pri = 0; (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);      // the chain kernel is the longest dependent piece of a launch: let its blocks be placed first
+            H2W_HIP(hipStreamCreateWithPriority(&p->side[k], hipStreamNonBlocking, hi_pri)); p->side_of[k] = stream; p->n_side++;
+        }
         if (k < p->n_side) cstream = p->side[k];      // (more caller streams than side streams: the extra ones do not fork)
     }
     p->n_batches++;
