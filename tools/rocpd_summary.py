@@ -29,8 +29,11 @@ def pmc(dbs, out):
         c = sqlite3.connect(db)
         for name, ctr, n, avg in c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
                                            "group by kernel_name, counter_name"):
-            scale = 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0)
-            res.setdefault(name, {})[ctr] = {"dispatches": n, "avg_raw_KB": avg, "avg_bytes_corrected": avg * scale}
+            if ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                scale = 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0)
+                res.setdefault(name, {})[ctr] = {"dispatches": n, "avg_raw_KB": avg, "avg_bytes_corrected": avg * scale}
+            else:
+                res.setdefault(name, {})[ctr] = {"dispatches": n, "avg_per_dispatch": avg}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
