@@ -45,6 +45,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 OPT_FORK_CHAINS = 1     # include/h2w.h H2W_OPT_FORK_CHAINS
+OPT_SERIAL_EXPAND = 2   # include/h2w.h H2W_OPT_SERIAL_EXPAND
 
 
 def cpu_baseline(shape_args, hash_mode, lookup_bits, budget_s=12.0):
@@ -133,15 +134,16 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--hash", default="bn254", choices=["bn254", "gl"])
     ap.add_argument("--batch", type=int, default=0, help="proofs per launch (0 = auto: ~58 GB of advice per launch)")
-    ap.add_argument("--streams", type=int, default=3, help="launches in flight, each on its own HIP stream with its own advice / workspace buffers")
+    ap.add_argument("--streams", type=int, default=4, help="launches in flight, each on its own HIP stream with its own advice / workspace buffers")
     ap.add_argument("--launches-per-step", type=int, default=12)
     ap.add_argument("--lookup-bits", type=int, default=21)
-    ap.add_argument("--advice-cap-gb", type=float, default=200.0, help="upper bound on the advice buffers of all launches in flight (the stream count is reduced to fit)")
+    ap.add_argument("--advice-cap-gb", type=float, default=250.0, help="upper bound on the advice buffers of all launches in flight (the stream count is reduced to fit)")
     ap.add_argument("--calib", type=int, default=3, help="isolated launches after the timed region (one at a time, chain kernel on the caller's stream) for the per-kernel roofline numbers")
     ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--shard-queries", action="store_true", help="N > 1: shard the (proof, query) units of the SAME proofs over the ranks (strong scaling; default for cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fork", action="store_true", help="experiment: PoseidonBN254 chain kernels on the caller's stream (H2W_OPT_FORK_CHAINS = 0)")
+    ap.add_argument("--serial-expand", type=int, default=-1, choices=[-1, 0, 1], help="H2W_OPT_SERIAL_EXPAND (-1: the library's default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -178,12 +180,16 @@ def main():
     plan = api.Plan(shape, consts, local_rank)
     if args.no_fork:
         plan.configure(OPT_FORK_CHAINS, 0)
+    if args.serial_expand >= 0:
+        plan.configure(OPT_SERIAL_EXPAND, args.serial_expand)
 
     cell_bytes = plan.num_cells * 32
     B = args.batch if args.batch > 0 else max(1, min(64, int(58.6e9 // cell_bytes)))
     S = max(1, args.streams)
     if args.share_gpu0:
         args.advice_cap_gb /= world
+    free_b, _total_b = torch.cuda.mem_get_info(dev)         # leave 16 GB for the workspaces, the proofs and the allocator
+    args.advice_cap_gb = min(args.advice_cap_gb, (free_b / (world if args.share_gpu0 else 1) - 16e9) / 1e9)
     while S > 1 and S * B * cell_bytes > args.advice_cap_gb * 1e9:   # stay inside the 288 GB of HBM
         S -= 1
     R = max(args.launches_per_step, 1)
@@ -273,6 +279,13 @@ def main():
     nback = min(args.steps * R, 64)
     tim = [plan.timing(i) for i in range(nback)]
     overl = [sum(t[k] for t in tim) / nback for k in range(5)]
+    # how the expansion kernels of successive launches lie against each other (H2W_EV_EXPAND_START = 6, _END = 7): the gap from the
+    # end of one to the start of the next (negative = they overlapped) and the spacing of their ends = the steady-state launch period
+    ng = min(nback - 1, 24)
+    gaps = [plan.event_gap(i + 1, 7, i, 6) for i in range(ng)]
+    period = [plan.event_gap(i + 1, 7, i, 7) for i in range(ng)]
+    schedule = {"launches": ng, "expand_end_to_next_expand_start_ms": {"avg": sum(gaps) / ng, "min": min(gaps), "max": max(gaps)},
+                "expand_end_to_next_expand_end_ms": {"avg": sum(period) / ng, "min": min(period), "max": max(period)}} if ng > 0 else None
     # (b) isolated: one launch at a time on one stream, the chain kernel on the same stream (no intra-launch overlap), so that every
     #     kernel's event interval is its own duration
     isol = None
@@ -340,6 +353,7 @@ def main():
             "advice_GBps": value * 32 / 1e9,
             "kernel_ms_isolated": dict(zip(keys, isol)) if isol else None,
             "kernel_ms_timed_region": dict(zip(keys, overl)),
+            "expand_schedule_timed_region": schedule,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS if achieved else None),
                          "traffic": None, "algorithmic_bytes": kbytes.get(dom), "kernel": names[dom], "kernels": kernels,
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS / world,

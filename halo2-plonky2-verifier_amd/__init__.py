@@ -155,6 +155,7 @@ SYMBOLS = {
     "h2w_plan_status": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint32), _vp]),
     "h2w_advice_digest": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "h2w_plan_last_timing": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "h2w_plan_event_gap": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_float)]),
     "h2w_plan_configure": (C.c_int, [_vp, C.c_int, C.c_int]),
     "h2w_plan_num_chain_cells": (C.c_uint64, [_vp]),
     "h2w_plan_strand_layout": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),

@@ -348,6 +348,12 @@ class Plan:
         _ck(self.L.h2w_plan_last_timing(self.p, ms), "h2w_plan_last_timing")
         return tuple(ms)
 
+    def event_gap(self, back_a, which_a, back_b, which_b):
+        """ms from event which_a of the call back_a before the last to event which_b of the call back_b before the last (H2W_EV_*)."""
+        ms = C.c_float()
+        _ck(self.L.h2w_plan_event_gap(self.p, back_a, which_a, back_b, which_b, C.byref(ms)), "h2w_plan_event_gap")
+        return float(ms.value)
+
 
 class Prover:
     """Synthetic valid FRI instances generated on the GPU (h2w_prover_* / h2w_prove_fri): the step before the

@@ -179,9 +179,10 @@ struct h2w_plan {
     PlanEqualities eqs;
     fr_t *d_bn_tab = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
-    static constexpr int EV_RING = 64, N_EV = 8, N_SIDE = 16;
-    hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 7 / 2 glue (+ Goldilocks Merkle strands) start / done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call
+    static constexpr int EV_RING = 64, N_EV = 9, N_SIDE = 16;
+    hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 7 / 2 glue (+ Goldilocks Merkle strands) start / done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call, 8 expansion start
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
+    int serial_expand = -1;          // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's (-1: on with PoseidonBN254 caps)
     bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
@@ -408,6 +409,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
         }
         if (k < p->n_side) cstream = p->side[k];      // (more caller streams than side streams: the extra ones do not fork)
     }
+    hipEvent_t *prev_ev = p->n_batches ? p->evr[(p->n_batches - 1) % h2w_plan::EV_RING] : nullptr;
     p->n_batches++;
     hipEvent_t *ev = p->ev;
     int dbg_skip = 0;
@@ -449,9 +451,19 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
     p->dt.fill(E);
     E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
-    H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
+#ifdef H2W_DEBUG_HOOKS
+    { static int dgx = -1; if (dgx < 0) { const char *e = getenv("H2W_DBG_EXPAND_GX"); dgx = e ? atoi(e) : 0; } if (dgx > 0) gx = dgx; }
+#endif
     if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, ev[2], 0));    // value strands done -> expansion on the emit stream
+    H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
+    // One expansion kernel at a time over all the streams a plan is driven on: its blocks are persistent and hold their CUs until the
+    // launch is written, so two of them side by side keep the latency-bound strands of the other launches in flight off the chip
+    // (measured: +8..12 % for the whole job with PoseidonBN254 caps, profiles/r02_sweep5.txt; with Goldilocks caps, where the
+    // expansion kernel is the only bulk writer, overlapping its launches is better).
+    const bool serial = p->serial_expand < 0 ? p->shape.hash_mode == 1 : p->serial_expand != 0;
+    if (serial && prev_ev && p->ev_recorded) H2W_HIP(hipStreamWaitEvent(estream, prev_ev[3], 0));
+    H2W_HIP(hipEventRecord(ev[8], estream));
     if (!(dbg_skip & 4)) launch_expand(E, n_proofs, gx, estream);
     H2W_HIP(hipEventRecord(ev[3], estream));
     if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, ev[3], 0));    // the caller's stream completes when the advice is complete
@@ -745,14 +757,26 @@ int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batch
     H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));   // prologue strands
     H2W_HIP(hipEventElapsedTime(&ms[1], ev[7], ev[2]));   // query glue strands (+ Goldilocks-Poseidon Merkle strands)
     H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[5]));   // PoseidonBN254 Merkle chain kernel (on its side stream; 0 for Goldilocks-Poseidon Merkle)
-    H2W_HIP(hipEventElapsedTime(&ms[3], ev[2], ev[3]));   // expansion kernel
+    H2W_HIP(hipEventElapsedTime(&ms[3], ev[8], ev[3]));   // expansion kernel
     H2W_HIP(hipEventElapsedTime(&ms[4], ev[0], ev[6]));   // whole call
     return 0;
 }
 int h2w_plan_last_timing(h2w_plan *p, float ms[5]) { return h2w_plan_timing(p, 0, ms); }
+int h2w_plan_event_gap(h2w_plan *p, uint64_t back_a, int which_a, uint64_t back_b, int which_b, float *ms) {
+    static const int idx[H2W_EV_COUNT] = {0, 1, 7, 2, 4, 5, 8, 3, 6};
+    if (!p || !ms || !p->ev_recorded || back_a >= p->n_batches || back_b >= p->n_batches || back_a >= (uint64_t)h2w_plan::EV_RING || back_b >= (uint64_t)h2w_plan::EV_RING ||
+        which_a < 0 || which_a >= H2W_EV_COUNT || which_b < 0 || which_b >= H2W_EV_COUNT) { set_error("h2w_plan_event_gap: no such batch / event"); return -1; }
+    if (p->shape.hash_mode == 0 && (which_a == H2W_EV_CHAINS_START || which_a == H2W_EV_CHAINS_END || which_b == H2W_EV_CHAINS_START || which_b == H2W_EV_CHAINS_END)) { set_error("h2w_plan_event_gap: no chain kernel with Goldilocks-Poseidon caps"); return -1; }
+    hipEvent_t a = p->evr[(p->n_batches - 1 - back_a) % h2w_plan::EV_RING][idx[which_a]], b = p->evr[(p->n_batches - 1 - back_b) % h2w_plan::EV_RING][idx[which_b]];
+    DeviceGuard dg(p->device);
+    H2W_HIP(hipEventSynchronize(a)); H2W_HIP(hipEventSynchronize(b));
+    H2W_HIP(hipEventElapsedTime(ms, a, b));
+    return 0;
+}
 int h2w_plan_configure(h2w_plan *p, int option, int value) {
     if (!p) { set_error("h2w_plan_configure: null plan"); return -1; }
     if (option == H2W_OPT_FORK_CHAINS) { p->fork_chains = value != 0; return 0; }
+    if (option == H2W_OPT_SERIAL_EXPAND) { p->serial_expand = value < 0 ? -1 : value != 0; return 0; }
     set_error("h2w_plan_configure: unknown option"); return -1;
 }
 

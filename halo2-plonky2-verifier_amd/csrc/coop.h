@@ -341,6 +341,9 @@ template <bool COLS> struct QuadSinkT {
         int l;
     };
     static __device__ __forceinline__ void put(const Em &e, int slot, const fr_t &v) {
+#ifdef H2W_DBG_NOPUT      // timing experiment (tools/build_debug_variant.sh): the results are garbage
+        if (e.l >= 0) return;
+#endif
         sq16_t *q = e.val + slot * BN_SLOT_SQ; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]};
     }
     static __device__ __forceinline__ void put_if(const Em &e, bool on, int slot, const fr_t &v) { if (on) put(e, slot, v); }
@@ -353,6 +356,9 @@ template <bool COLS> struct QuadSinkT {
     template <int N, class MapFn> __device__ __forceinline__ void flush_layer(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
         constexpr int NP = (N + 1) / 2;
         const bool hiq = e.l >= 2;
+#ifdef H2W_DBG_NOFLUSH    // timing experiment (tools/build_debug_variant.sh): bookkeeping only, no cell is written
+        if (e.l >= 0) { e.cell0 += (uint64_t)N; e.gdst += (unsigned long long)N * 32; return; }
+#endif
         if constexpr (COLS) {
             if (cc.hi - e.cell0 < (uint64_t)N || e.cell0 < cc.lo) { flush_layer_cols<N>(e, map, baseA, baseB); return; }
         }

@@ -271,6 +271,10 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
  * runs on a library-owned side stream beside the query-glue and expansion kernels of the same call (they depend on the prologue
  * only); the caller's stream still completes when the whole advice is written.  0: every kernel on the caller's stream. */
 #define H2W_OPT_FORK_CHAINS 1
+/* H2W_OPT_SERIAL_EXPAND (default -1 = automatic: 1 with PoseidonBN254 caps, 0 with Goldilocks caps): the expansion kernel of a batch call
+ * waits for the expansion kernel of the plan's previous batch call, whatever stream that was issued on, so that the latency-bound
+ * strands of the other calls in flight find free CUs; the cells written are the same either way. */
+#define H2W_OPT_SERIAL_EXPAND 2
 int h2w_plan_configure(h2w_plan *, int option, int value);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the streams it launches on:
  * ms[0] = prologue strands, ms[1] = query glue strands (+ Goldilocks-Poseidon Merkle strands), ms[2] = PoseidonBN254 Merkle
@@ -278,6 +282,19 @@ int h2w_plan_configure(h2w_plan *, int option, int value);
  * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
 int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
 int h2w_plan_last_timing(h2w_plan *, float ms[5]);
+/* Elapsed ms from event `which_a` of the batch call `back_a` calls before the last one to event `which_b` of the call `back_b` before
+ * the last one (negative when b came first): how the kernels of different calls lie against each other on the device. */
+#define H2W_EV_CALL_START 0
+#define H2W_EV_PROLOGUE_END 1
+#define H2W_EV_GLUE_START 2
+#define H2W_EV_GLUE_END 3
+#define H2W_EV_CHAINS_START 4
+#define H2W_EV_CHAINS_END 5
+#define H2W_EV_EXPAND_START 6
+#define H2W_EV_EXPAND_END 7
+#define H2W_EV_CALL_END 8
+#define H2W_EV_COUNT 9
+int h2w_plan_event_gap(h2w_plan *, uint64_t back_a, int which_a, uint64_t back_b, int which_b, float *ms);
 /* Advice cells per proof written by the expansion kernel (the rest are written directly by the value kernels). */
 uint64_t h2w_plan_num_record_cells(const h2w_plan *);
 /* Advice cells per proof of the MerkleTreeChip::verify_proof_to_cap_with_cap_index calls (merkle/mod.rs:57-78): with PoseidonBN254

@@ -357,3 +357,44 @@ def test_two_plans_with_different_tables_interleaved_on_two_streams(h2w, h2w_api
         assert advice.cpu().numpy().tobytes() == want[k]
     for pl in plans:
         pl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_scheduling_options_do_not_change_the_cells(h2w, h2w_api, oracle, consts, mode):
+    """H2W_OPT_FORK_CHAINS / H2W_OPT_SERIAL_EXPAND only move kernels between streams and order them with events: one plan driven on
+    three streams with every combination of the two options, all launches enqueued before anything is waited for, each launch into
+    its own buffers; every launch's stream is the oracle's."""
+    import torch
+    ko, kh = consts
+    sh = h2w.fibonacci_shape(8, 3, rate_bits=1, hash_mode=mode, cap_height=1); osh = oracle.fibonacci_shape(8, 3, rate_bits=1, hash_mode=mode, cap_height=1)
+    plan = h2w_api.Plan(sh, kh)
+    n = 3
+    proofs = [oracle.synth_proof(osh, 900 + i) for i in range(n)]
+    host = torch.empty(n * plan.proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda()
+    want = b""
+    for p in proofs:
+        ctx = oracle.Ctx(21)
+        assert oracle.verify_stark(ctx, osh, ko, p) == 0
+        want += ctx.advice_bytes(); ctx.close()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = []
+    for fork in (1, 0):
+        for serial in (1, 0, -1):
+            for s in range(3):
+                outs.append((fork, serial, s, torch.zeros(n * plan.num_cells * 32, dtype=torch.uint8, device="cuda"),
+                             torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize()
+    for fork, serial, s, advice, ws in outs:
+        plan.configure(1, fork); plan.configure(2, serial)         # include/h2w.h: H2W_OPT_FORK_CHAINS = 1, H2W_OPT_SERIAL_EXPAND = 2
+        plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), streams[s].cuda_stream)
+    torch.cuda.synchronize()
+    for fork, serial, s, advice, ws in outs:
+        assert plan.status(ws.data_ptr(), n) == [0] * n
+        assert advice.cpu().numpy().tobytes() == want, (fork, serial, s)
+    with pytest.raises(Exception):
+        plan.configure(99, 0)
+    plan.close()

@@ -1,0 +1,9 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for rep in 1 2; do
+for args in "--serial 1 --streams 4 --batch 64 --advice-cap-gb 250" "--serial 1 --streams 6 --batch 32" "--serial 1 --streams 5 --batch 48 --advice-cap-gb 250" "--serial 1 --streams 6 --batch 40 --advice-cap-gb 250" "--serial 1 --streams 3 --batch 64" "--serial 1 --streams 5 --batch 40"; do
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --calib 0 $args > gpurun_out/r02_bench_s.log 2>&1 || { tail -20 gpurun_out/r02_bench_s.log; exit 1; }
+python3 -c "
+import json;d=json.loads(open('gpurun_out/r02_bench_s.log').read().strip().splitlines()[-1]);print('$args', 'G', round(d['value']/1e9,1), 'ms/launch', round(d['ms_per_step']/12,3), 'timed', {k:round(v,2) for k,v in d['kernel_ms_timed_region'].items()})"
+done
+done

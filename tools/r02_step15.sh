@@ -1,0 +1,7 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for args in "--serial 4 --streams 4 --batch 64 --advice-cap-gb 250" "--serial 4 --streams 6 --batch 32" "--hash gl --serial 4" "--hash gl --serial 4 --streams 4 --advice-cap-gb 250" "--hash gl --streams 4 --advice-cap-gb 250" "--hash gl --streams 2"; do
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --calib 0 $args > gpurun_out/r02_bench_s.log 2>&1 || { tail -20 gpurun_out/r02_bench_s.log; exit 1; }
+python3 -c "
+import json;d=json.loads(open('gpurun_out/r02_bench_s.log').read().strip().splitlines()[-1]);print('$args', 'G', round(d['value']/1e9,1), 'ms/launch', round(d['ms_per_step']/12,3), 'timed', {k:round(v,2) for k,v in d['kernel_ms_timed_region'].items()})"
+done
