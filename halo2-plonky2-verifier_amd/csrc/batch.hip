@@ -68,7 +68,10 @@ struct PlanSink {
 // Register budget of the strand kernels (the attribute propagates to their callees): H2W_QUAD_WAVES wavefronts per SIMD.
 #define H2W_WAVES __attribute__((amdgpu_waves_per_eu(1, 1)))
 // the PoseidonBN254 chain kernel: two blocks of QUAD_BLOCK threads per CU by LDS (32.9 KB of tables + 10 KB of value slots per wavefront)
-#define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef H2W_QUAD_EU
+#define H2W_QUAD_EU 2
+#endif
+#define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(H2W_QUAD_EU, H2W_QUAD_EU)))
 template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_prologue(BatchArgs A) {
     typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +86,7 @@ template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_prologue(
 // one wavefront per proof: wave-uniform gadget code, Goldilocks Poseidon split over 12 lanes (coop.h)
 template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
     typedef CoopSinkT<COLS> CoopSink; typedef ValBackend<CoopSink> CoopB;
-    __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
+    if (!(A.dbg_prio & 1)) __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
     CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm; sink.cc.init(A.cm);
@@ -98,7 +101,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_coop(Batch
 // Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot
 template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
     typedef CoopSinkT<COLS> CoopSink; typedef ValBackend<CoopSink> CoopB;
-    __builtin_amdgcn_s_setprio(3);
+    if (!(A.dbg_prio & 2)) __builtin_amdgcn_s_setprio(3);
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int idx = blockIdx.x, nq = A.shape.num_queries;
     const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
@@ -393,9 +396,10 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm; A.shard_rank = shard_rank; A.shard_world = shard_world;
     A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
     A.bn_tab = p->d_bn_tab; A.role_base = 0;
-    A.dbg_skip_perm = 0;
+    A.dbg_skip_perm = 0; A.dbg_prio = 0;
 #ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/): never defined in the product build, the results are garbage
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e ? atoi(e) : 0; } A.dbg_skip_perm = dbg; }
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_PRIO"); dbg = e ? atoi(e) : 0; } A.dbg_prio = dbg; }      // 1: prologue, 2: Goldilocks Merkle strands without s_setprio; 4: glue strands with it
 #endif
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;

@@ -15,7 +15,7 @@ struct BatchArgs {
     DevCB *cbs; uint32_t *status;
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
     StrandTable st; FrParams P;
-    int nproofs, role_base, dbg_skip_perm;
+    int nproofs, role_base, dbg_skip_perm, dbg_prio;
     const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
     ColMap cm;      // column-major emission (starts == nullptr: flat advice)

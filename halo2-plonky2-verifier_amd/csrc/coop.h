@@ -273,6 +273,14 @@ template <int J> __device__ __forceinline__ fr_t quad_bcast(const fr_t &v) { ret
 __device__ __forceinline__ fr_t quad_up1(const fr_t &v) { return quad_dpp<0x90>(v); }                            // lane i <- lane i - 1 (lane 0 keeps its own)
 __device__ __forceinline__ fr_t quad_up2(const fr_t &v) { return quad_dpp<0x44>(v); }                            // lanes 2, 3 <- lanes 0, 1
 
+// limb-wise select: `c ? a : b` on the struct itself can be lowered to a select of two stack addresses plus a scratch load, and a scratch
+// load waits (vmcnt is in order on this family) for every cell store issued before it
+__device__ __forceinline__ fr_t fr_sel(bool c, const fr_t &a, const fr_t &b) {
+    fr_t r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
 // one cell source of a layer: a value slot of the quad, a table entry, or a table entry relative to one of two per-layer bases
 struct BnSrc { int kind, idx; };                              // kind 0: value slot; 1: table entry; 2: entry base A + idx; 3: entry base B + idx
 constexpr BnSrc bV(int s) { return BnSrc{0, s}; }
@@ -384,6 +392,25 @@ template <bool COLS> struct QuadSinkT {
         }
         e.cell0 += (uint64_t)N; e.gdst += (unsigned long long)N * 32;
     }
+    // The same stream in two halves around other work: part_load issues the LDS reads of pieces [K0, K1) of a layer, part_store their
+    // stores.  The partial rounds flush round r - 1 this way between the products of round r (four parts), so that no read is waited for
+    // and the flush costs its issue slots only (the one wavefront of a SIMD has nobody to hide an s_waitcnt behind).
+    template <int K0, int K1, int N, class MapFn> static __device__ __forceinline__ void part_load(const Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB, sq16_t *t) {
+        const bool hiq = e.l >= 2;
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            const sq16_t *pa = src_ptr(e, map, 2 * k, baseA, baseB), *pb = (2 * k + 1 < N) ? src_ptr(e, map, 2 * k + 1, baseA, baseB) : pa;
+            t[k - K0] = *(hiq ? pb : pa);
+        }
+    }
+    template <int K0, int K1, int N> static __device__ __forceinline__ void part_store(const Em &e, const sq16_t *t) {
+        const bool hiq = e.l >= 2;
+#pragma unroll
+        for (int k = K0; k < K1; k++) {
+            unsigned long long *g = reinterpret_cast<unsigned long long *>(e.gdst + (unsigned long long)k * 64);
+            if (2 * k + 1 < N || !hiq) { H2W_GSTORE64(g, t[k - K0].x); H2W_GSTORE64(g + 1, t[k - K0].y); }
+        }
+    }
     // column-major layout, a layer that crosses into the next column (rare): per-cell addresses
     template <int N, class MapFn> __device__ __noinline__ void flush_layer_cols(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
         if constexpr (COLS) {
@@ -416,7 +443,7 @@ template <bool COLS> struct QuadSinkT {
         e.tabh = s_bn_tab + (l & 1);
         e.cell0 = cell_off;
         e.gdst = reinterpret_cast<unsigned long long>(out + cc.map(cell_off)) + (unsigned long long)l * 16;
-        fr_t s = l == 0 ? st[0] : l == 1 ? st[1] : l == 2 ? st[2] : st[3];
+        fr_t s = fr_sel(l < 2, fr_sel(l == 0, st[0], st[1]), fr_sel(l == 2, st[2], st[3]));
         auto exp5_all = [&]() {                          // S-box on every lane
             const fr_t X = fr_mont_mul(s, r2, ninv);
             const fr_t x2 = fr_mont_mul(s, X, ninv), X2 = fr_mont_mul(X, X, ninv);
@@ -459,26 +486,36 @@ template <bool COLS> struct QuadSinkT {
                     //   C: lane 0  x4 = x2 X2 ;  D: lane 0  x5 = x4 X ;  then s0' = x5 + c
                     //   E: lane 0  S_0 * s0'         | lanes 1-3  S'_k * s0'         (column update)
                     const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, lm = l > 0 ? l - 1 : 0, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                    // the previous round's layer (still staged: this round's values are put after product D) leaves between the products
+                    const bool pend = !COLS && r > 0;
+                    const sq16_t *pA = e.tabh + (ix - (BN_WIDTH * 2 - 1)) * 2, *pB = e.tabh + (ic - 1) * 2;
+                    sq16_t t0[7], t1[7], t2[6], t3[6];
                     const fr_t ksxm = bnk(1, ix + l);
-                    const fr_t A_ = fr_mont_mul(s, l == 0 ? r2 : ksxm, ninv);
+                    if (pend) part_load<0, 7, 52>(e, bn_map_partial, pA, pB, t0);
+                    const fr_t A_ = fr_mont_mul(s, fr_sel(l == 0, r2, ksxm), ninv);
+                    if (pend) { part_store<0, 7, 52>(e, t0); part_load<7, 14, 52>(e, bn_map_partial, pA, pB, t1); }
                     const fr_t Xb = quad_bcast<0>(A_);
-                    const fr_t B_ = fr_mont_mul(l == 0 ? s : Xb, Xb, ninv);
+                    const fr_t B_ = fr_mont_mul(fr_sel(l == 0, s, Xb), Xb, ninv);
+                    if (pend) { part_store<7, 14, 52>(e, t1); part_load<14, 20, 52>(e, bn_map_partial, pA, pB, t2); }
                     const fr_t X2b = quad_bcast<1>(B_);
-                    const fr_t x4 = fr_mont_mul(B_, X2b, ninv), x5 = fr_mont_mul(x4, Xb, ninv);
+                    const fr_t x4 = fr_mont_mul(B_, X2b, ninv);
+                    if (pend) { part_store<14, 20, 52>(e, t2); part_load<20, 26, 52>(e, bn_map_partial, pA, pB, t3); }
+                    const fr_t x5 = fr_mont_mul(x4, Xb, ninv);
+                    if (pend) { part_store<20, 26, 52>(e, t3); e.cell0 += 52; e.gdst += 52ull * 32; }
                     const fr_t s0n = fr_add(x5, bnk(0, ic));
                     put(e, l, s);                                        // slots 0-3: the state before the round
                     put_if(e, l == 0, 4, B_); put_if(e, l == 0, 5, x4); put_if(e, l == 0, 6, x5); put_if(e, l == 0, 7, s0n);
                     const fr_t s0 = quad_bcast<0>(s0n);
-                    const fr_t E_ = fr_mont_mul(s0, l == 0 ? ksxm : bnk(1, ix + BN_WIDTH + lm), ninv);
-                    fr_t incl = l == 0 ? E_ : A_;                        // S[j] * s_j, then the running sums over the quad
+                    const fr_t E_ = fr_mont_mul(s0, fr_sel(l == 0, ksxm, bnk(1, ix + BN_WIDTH + lm)), ninv);
+                    fr_t incl = fr_sel(l == 0, E_, A_);                        // S[j] * s_j, then the running sums over the quad
                     { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
                     { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
                     put(e, 8 + l, incl);
                     const fr_t nv = fr_add(E_, s);
                     put_if(e, l > 0, 12 + lm, nv);
                     const fr_t ns0 = quad_bcast<3>(incl);
-                    s = l > 0 ? nv : ns0;
-                    flush_layer<52>(e, bn_map_partial, e.tabh + ix * 2, e.tabh + ic * 2);
+                    s = fr_sel(l > 0, nv, ns0);
+                    if (COLS || r == BN_PARTIAL_ROUNDS - 1) flush_layer<52>(e, bn_map_partial, e.tabh + ix * 2, e.tabh + ic * 2);
                 }
             }
             // full_rounds(is_first = half == 0) (:112-160): load_constant of M and P, then 4 x (x^5, [ark], mix)

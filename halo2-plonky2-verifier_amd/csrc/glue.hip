@@ -16,6 +16,7 @@ namespace h2w {
 
 template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_strands(BatchArgs A) {
     typedef DevSinkT<COLS, true> GlueSink; typedef ValBackend<GlueSink> GlueB;
+    if (A.dbg_prio & 4) __builtin_amdgcn_s_setprio(3);      // (experiment switch: always 0 in the product build)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = A.shape.num_queries;
     if (idx >= A.nproofs * nq) return;

@@ -8,5 +8,6 @@ cd "$(dirname "$0")/../halo2-plonky2-verifier_amd/csrc"
 FLAGS="-DH2W_DEBUG_HOOKS $H2W_EXTRA -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wno-unused-value -x hip"
 mkdir -p ../build_$name
 hipcc $FLAGS -c batch.hip -o ../build_$name/batch.o
-hipcc --offload-arch=gfx950 -shared -fPIC ../build/expand.o ../build/eager.o ../build_$name/batch.o ../build/glue.o ../build/chipbatch.o ../build/abi_backend.o ../build/prover.o -o ../libh2w_$name.so
+hipcc $FLAGS -c glue.hip -o ../build_$name/glue.o
+hipcc --offload-arch=gfx950 -shared -fPIC ../build/expand.o ../build/eager.o ../build_$name/batch.o ../build_$name/glue.o ../build/chipbatch.o ../build/abi_backend.o ../build/prover.o -o ../libh2w_$name.so
 echo "built $(realpath ../libh2w_$name.so)"
