@@ -325,7 +325,9 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
                 // steps in which this lane's cell 8 c + kc is one of the record's: c in [c_lo, c_hi]
                 const int c_lo = (vs_ - kc + 7) >> 3, c_hi = ve_ - 1 - kc >= 0 ? (ve_ - 1 - kc) >> 3 : -1;
                 const unsigned char *rd = hi ? hi_base : rd_base + g * 4 * ROW;                   // low halves from the record's row, high halves from the template row
-                unsigned char *const dst = out_half + ((ull)br.x + (ull)(uint32_t)kc) * 32;       // + 256 c per step: an immediate offset
+                // (br.x = cell index of virtual cell 0, mod 2^32: negative when the stream starts inside the record's virtual list, e.g. a LOADW
+                //  block at cell 0; the steps that are stored, c >= c_lo, land at or after the record's first real cell)
+                unsigned char *const dst = out_half + ((long long)(uint32_t)(br.x + (uint32_t)kc + 16u) - 16) * 32;       // (>= -8; streams of up to 2^32 - 32 cells) + 256 c per step: an immediate offset
                 if (__all(c_lo <= 1 && c_hi >= NCH - 2)) {       // four whole Goldilocks-op blocks (the usual case): only the first and the last step are ragged
                     if (c_lo <= 0) *reinterpret_cast<u128s *>(dst) = *reinterpret_cast<const u128s *>(rd);
 #pragma unroll

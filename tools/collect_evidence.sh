@@ -11,6 +11,7 @@ for tag in default s1; do
   if [ $tag = default ]; then ARGS="--no-cpu-baseline --calib 0 --steps 4 --warmup 2"; else ARGS="$S1"; fi
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o r -- python3 bench.py $ARGS > gpurun_out/prof_$tag.log 2>&1
   python3 tools/rocpd_summary.py stats gpurun_out/prof_$tag/r_results.db gpurun_out/r02_${tag}_kernel_stats.csv
+  if [ $tag = default ]; then python3 tools/rocpd_summary.py overlap gpurun_out/prof_$tag/r_results.db gpurun_out/r02_overlap_under_rocprof.txt; fi
   cut -c1-120 gpurun_out/r02_${tag}_kernel_stats.csv | head -6
 done
 for ctr in WRITE_SIZE FETCH_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
