@@ -397,4 +397,15 @@ def test_scheduling_options_do_not_change_the_cells(h2w, h2w_api, oracle, consts
         assert advice.cpu().numpy().tobytes() == want, (fork, serial, s)
     with pytest.raises(Exception):
         plan.configure(99, 0)
+    # the library's event accessor (H2W_EV_*: 6 / 7 = expansion start / end, 0 / 8 = call start / end): with the expansion kernels serialised the
+    # next one never starts before the previous one ended, whatever stream it is on
+    plan.configure(1, 1); plan.configure(2, 1)
+    for _, _, s, advice, ws in outs[:6]:
+        plan.run(d_proofs.data_ptr(), n, advice.data_ptr(), ws.data_ptr(), streams[s].cuda_stream)
+    torch.cuda.synchronize()
+    for back in range(5):
+        assert plan.event_gap(back, 6, back, 7) > 0 and plan.event_gap(back, 0, back, 8) > 0
+        assert plan.event_gap(back + 1, 7, back, 6) >= 0
+    with pytest.raises(Exception):
+        plan.event_gap(0, 0, 0, 99)
     plan.close()
