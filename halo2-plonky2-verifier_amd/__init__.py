@@ -168,6 +168,13 @@ SYMBOLS = {
     "h2w_chipbatch_num_operands": (C.c_uint64, [_vp]),
     "h2w_chipbatch_num_cells": (C.c_uint64, [_vp]),
     "h2w_chipbatch_run": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "h2w_comm_unique_id": (C.c_int, [_vp]),
+    "h2w_comm_init": (_vp, [_vp, C.c_int, C.c_int, C.c_int]),
+    "h2w_comm_free": (None, [_vp]),
+    "h2w_comm_rank": (C.c_int, [_vp]),
+    "h2w_comm_world": (C.c_int, [_vp]),
+    "h2w_comm_broadcast_proofs": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, _vp]),
+    "h2w_comm_allgather_digests": (C.c_int, [_vp, _vp, _vp, _vp]),
     "h2w_plan_timing": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
     "h2w_plan_num_record_cells": (C.c_uint64, [_vp]),
     "h2w_prover_new": (_vp, [C.POINTER(Shape), C.POINTER(PoseidonConsts), C.c_int]),

@@ -60,3 +60,39 @@ def shard_ranges(n_proofs, num_queries, rank, world, layout):
             if unit_owner(p, q, num_queries, world) == rank:
                 out.append((p, pro, q0) if q == 0 else (p, pro + q0 + (q - 1) * qn, qn))
     return out
+
+
+class Comm:
+    """The C-ABI ingest communicator (include/h2w.h h2w_comm_*: RCCL resolved inside libh2w.so), for callers without torch.distributed.
+    `id128` comes from Comm.unique_id() on one rank and reaches the others by any out-of-band channel."""
+
+    def __init__(self, lib, id128, rank, world, device_id=0):
+        import ctypes as C
+        self.L = lib
+        self._id = (C.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        self.p = lib.h2w_comm_init(self._id, rank, world, device_id)
+        if not self.p:
+            raise RuntimeError(lib.h2w_last_error().decode())
+
+    @staticmethod
+    def unique_id(lib):
+        import ctypes as C
+        buf = (C.c_ubyte * 128)()
+        if lib.h2w_comm_unique_id(buf) != 0:
+            raise RuntimeError(lib.h2w_last_error().decode())
+        return bytes(buf)
+
+    def broadcast_proofs(self, proofs, root=0, stream=0):
+        """In place, int64 device tensor."""
+        if self.L.h2w_comm_broadcast_proofs(self.p, proofs.data_ptr(), proofs.numel(), root, stream) != 0:
+            raise RuntimeError(self.L.h2w_last_error().decode())
+        return proofs
+
+    def allgather_digests(self, digest4, out, stream=0):
+        if self.L.h2w_comm_allgather_digests(self.p, digest4.data_ptr(), out.data_ptr(), stream) != 0:
+            raise RuntimeError(self.L.h2w_last_error().decode())
+        return out
+
+    def close(self):
+        if self.p:
+            self.L.h2w_comm_free(self.p); self.p = None

@@ -264,6 +264,21 @@ int h2w_plan_status(h2w_plan *, const void *workspace_dev, uint64_t n_proofs, ui
  * back): digest[j] = sum over cells i of limb_j(cell i) * ((((i + 1) * 0x9E3779B97F4A7C15) | 1) + 2 j)  mod 2^64 - position-dependent,
  * order-independent in its evaluation.  digest4_dev: 4 x u64, device.  One call per proof. */
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream);
+/* ---- Multi-GPU ingest: one process per GPU, no data-path collective.  The only exchange is ONE broadcast of the flat proof block
+ * from the ingest rank (RCCL over xGMI); after it every rank runs h2w_fri_witness_batch on its own proofs or h2w_fri_witness_batch_shard on
+ * its (proof, query) units.  Optionally the ranks gather each other's h2w_advice_digest words.  RCCL is loaded at the first call here
+ * (dlopen), so the rest of the library works without it.  Replaces, for a caller without torch.distributed, what bench.py does with
+ * dist.broadcast; the reference has no counterpart (single process, fri/mod.rs:488-501 is the loop being sharded).
+ * id: H2W_COMM_ID_BYTES bytes made by h2w_comm_unique_id on one rank and handed to the others by any out-of-band channel. */
+#define H2W_COMM_ID_BYTES 128
+typedef struct h2w_comm h2w_comm;
+int h2w_comm_unique_id(void *id128);
+h2w_comm *h2w_comm_init(const void *id128, int rank, int world, int device_id);      /* collective: every rank calls it */
+void h2w_comm_free(h2w_comm *);
+int h2w_comm_rank(const h2w_comm *);
+int h2w_comm_world(const h2w_comm *);
+int h2w_comm_broadcast_proofs(h2w_comm *, uint64_t *proofs_dev, uint64_t n_words, int root, void *stream);      /* in place */
+int h2w_comm_allgather_digests(h2w_comm *, const uint64_t *digest4_dev, uint64_t *all_dev /* [world][4] */, void *stream);
 /* Output format: the stream is canonical little-endian Fr (what Fr::from_repr / to_repr use).  For a consumer that copies cells into
  * halo2curves' in-memory representation (Montgomery form, R = 2^256) this converts n_cells cells in place on the device. */
 int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);

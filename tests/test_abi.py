@@ -109,3 +109,18 @@ def test_published_tables_are_a_plain_data_call(h2w):
     assert "null" in h2w.last_error()
     k = h2w.published_consts()
     assert k.mds_circ[0] == 17 and k.mds_diag[0] == 8 and k.all_round_constants[0] == 0xb585f766f2144405
+
+
+def test_comm_entry_points_fail_loudly_without_a_device(h2w):
+    """The ingest communicator (h2w_comm_*) validates its arguments and needs a HIP device: no silent single-rank stand-in."""
+    import torch
+    L = h2w.lib()
+    assert L.h2w_comm_unique_id(None) != 0 and "null" in h2w.last_error()
+    ident = (C.c_ubyte * 128)()
+    assert not L.h2w_comm_init(ident, 2, 2, 0) and "rank" in h2w.last_error()          # rank outside the world
+    assert not L.h2w_comm_init(None, 0, 1, 0)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device branch is not reachable here")
+    assert not L.h2w_comm_init(ident, 0, 1, 0) and "no HIP device" in h2w.last_error()
+    assert L.h2w_comm_rank(None) == -1 and L.h2w_comm_world(None) == 0
+    L.h2w_comm_free(None)

@@ -409,3 +409,27 @@ def test_scheduling_options_do_not_change_the_cells(h2w, h2w_api, oracle, consts
     with pytest.raises(Exception):
         plan.event_gap(0, 0, 0, 99)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_comm_world_of_one(h2w, h2w_api):
+    """h2w_comm_* on the one GPU of the test box: a world of one rank (RCCL refuses two ranks on one device) - id, init, the in-place
+    proof broadcast and the digest all-gather run through RCCL and leave the data as it was."""
+    import importlib
+    import torch
+    D = importlib.import_module("halo2-plonky2-verifier_amd.distributed")
+    L = h2w.lib()
+    ident = D.Comm.unique_id(L)
+    assert len(ident) == 128
+    comm = D.Comm(L, ident, 0, 1, 0)
+    assert L.h2w_comm_rank(comm.p) == 0 and L.h2w_comm_world(comm.p) == 1
+    proofs = torch.arange(1, 4097, dtype=torch.int64, device="cuda")
+    want = proofs.clone()
+    comm.broadcast_proofs(proofs)
+    dig = torch.tensor([11, 22, 33, 44], dtype=torch.int64, device="cuda"); out = torch.zeros(4, dtype=torch.int64, device="cuda")
+    comm.allgather_digests(dig, out)
+    torch.cuda.synchronize()
+    assert torch.equal(proofs, want) and torch.equal(out, dig)
+    with pytest.raises(RuntimeError):
+        comm.broadcast_proofs(proofs, root=1)
+    comm.close()
