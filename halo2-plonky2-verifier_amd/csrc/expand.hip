@@ -240,9 +240,11 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[EXPAND_THREADS / 64][TILE];
     __shared__ uint2 s_vbr[EXPAND_THREADS / 64][FAST_T];     // per record: {flat index of its virtual cell 0, vs | ve << 8}
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t proof = blockIdx.y;
-    const rec_t *recs = A.recs + proof * A.rec_stride;
-    unsigned char *outb = reinterpret_cast<unsigned char *>(A.out + proof * A.cell_stride);
+    // which proof: one column of the grid per proof (static), or - roam - a grid of as many blocks as the chip holds at once, whose wavefronts
+    // start spread over the proofs and move on to the next proof that has tiles left.  With more blocks than fit, the late ones start when
+    // the first proofs are done and ramp up again: 5.5-5.8 TB/s for a launch alone against 6.3 with every block resident from the start
+    // (profiles/r02_expand_grid.txt).
+    uint64_t proof = A.roam ? (uint64_t)((blockIdx.x * (EXPAND_THREADS / 64) + wv) % A.nproofs) : (uint64_t)blockIdx.y;
     const uint32_t ntiles = (uint32_t)((A.nrec + 63) / 64);
     // -2^RB mod r (the one 254-bit constant of check_less_than): limbs of r with bit RB taken out of limb 1 (no borrow)
     const ull neg0 = H2W_FR_M0, neg1 = H2W_FR_M1 - (1ull << (M::RB - 64)), neg2 = H2W_FR_M2, neg3 = H2W_FR_M3;
@@ -251,10 +253,13 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
     const int piece = lane & 15, kc = piece >> 1; const bool hi = piece & 1;
     const unsigned char *rd_base = &s_tile[wv][(lane >> 4) * ROW + kc * 16];
     const unsigned char *hi_base = &s_tile[wv][FAST_T * ROW + kc * 16];
-    unsigned char *const out_half = outb + (hi ? 16 : 0);
     for (int v = lane; v < M::VT; v += 64)
         *reinterpret_cast<u128s *>(&s_tile[wv][FAST_T * ROW + v * 16]) = fast_is_neg<L>(v) ? u128s{neg2, neg3} : u128s{0, 0};
 
+  for (;;) {
+    const rec_t *recs = A.recs + proof * A.rec_stride;
+    unsigned char *outb = reinterpret_cast<unsigned char *>(A.out + proof * A.cell_stride);
+    unsigned char *const out_half = outb + (hi ? 16 : 0);
     uint32_t tile;
     { uint32_t t0 = 0; if (lane == 0) t0 = atomicAdd(&A.tile_ctr[proof], 1u); tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0); }
     while (tile < ntiles) {
@@ -349,6 +354,18 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
         }
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
     }
+    if (!A.roam) break;
+    // the next proof (cyclically) whose counter says tiles are left: 64 counters per look.  A stale or racing read only costs a visit.
+    int nx = -1;
+    for (uint32_t base = 0; base < A.nproofs && nx < 0; base += 64) {
+        const uint32_t k = base + (uint32_t)lane; uint32_t idx = (uint32_t)proof + 1 + k; idx %= A.nproofs;
+        const uint32_t c = k < A.nproofs ? __hip_atomic_load(&A.tile_ctr[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        const unsigned long long m = __ballot(c < ntiles);
+        if (m) nx = (int)(((uint32_t)proof + 1 + base + (uint32_t)(__ffsll((long long)m) - 1)) % A.nproofs);
+    }
+    if (nx < 0) break;
+    proof = (uint64_t)__builtin_amdgcn_readfirstlane(nx);
+  }
 }
 
 // every template id a batched plan emits is fixed (< T_DYNAMIC; dynamic range-check templates and literal runs are eager-context
@@ -359,10 +376,27 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
     if (fast_ok && (A.lookup_bits == 21 || A.lookup_bits == 13 || A.lookup_bits == 8)) {
         const uint64_t ntiles = (A.nrec + 63) / 64;
         uint64_t gx = (uint64_t)grid_x; if (gx * (EXPAND_THREADS / 64) > ntiles) gx = (ntiles + EXPAND_THREADS / 64 - 1) / (EXPAND_THREADS / 64); if (gx < 1) gx = 1;
-        const dim3 grid((unsigned)gx, (unsigned)nproofs);
-        if (A.lookup_bits == 21) hipLaunchKernelGGL(expand_fast<21>, grid, dim3(EXPAND_THREADS), 0, stream, A);
-        else if (A.lookup_bits == 13) hipLaunchKernelGGL(expand_fast<13>, grid, dim3(EXPAND_THREADS), 0, stream, A);
-        else hipLaunchKernelGGL(expand_fast<8>, grid, dim3(EXPAND_THREADS), 0, stream, A);
+        ExpandArgs B = A; B.nproofs = (uint32_t)nproofs; B.roam = 0;
+        dim3 grid((unsigned)gx, (unsigned)nproofs);
+        // roaming wavefronts: a batch of proofs with many tiles each (the witness path); many small instances (h2w_chipbatch) keep one column each
+        const uint64_t waves = EXPAND_THREADS / 64;
+        bool roam_ok = A.allow_roam && ntiles >= 64 && nproofs <= 4096 && grid_x > 0;
+#ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/build_debug_variant.sh)
+        { static int no = -1; if (no < 0) { const char *e = getenv("H2W_DBG_NO_ROAM"); no = e ? atoi(e) : 0; } if (no) roam_ok = false; }
+#endif
+        if (roam_ok) {
+            static int cus[64] = {0}; int dev = 0; (void)hipGetDevice(&dev);
+            if (dev >= 0 && dev < 64 && !cus[dev]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = n > 0 ? n : 256; }
+            const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+            const int per_cu = A.lookup_bits == 21 ? 2 : 1;                      // blocks of this kernel one CU holds (LDS)
+            uint64_t nb = (uint64_t)ncu * per_cu;
+            const uint64_t want = (ntiles * nproofs + waves - 1) / waves; if (nb > want) nb = want;
+            if (nb < 1) nb = 1;
+            B.roam = 1; grid = dim3((unsigned)nb, 1);
+        }
+        if (A.lookup_bits == 21) hipLaunchKernelGGL(expand_fast<21>, grid, dim3(EXPAND_THREADS), 0, stream, B);
+        else if (A.lookup_bits == 13) hipLaunchKernelGGL(expand_fast<13>, grid, dim3(EXPAND_THREADS), 0, stream, B);
+        else hipLaunchKernelGGL(expand_fast<8>, grid, dim3(EXPAND_THREADS), 0, stream, B);
         return;
     }
     const int TILE_RECS = 32;

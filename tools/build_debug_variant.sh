@@ -9,5 +9,6 @@ FLAGS="-DH2W_DEBUG_HOOKS $H2W_EXTRA -O3 -std=c++17 --offload-arch=gfx950 -fPIC -
 mkdir -p ../build_$name
 hipcc $FLAGS -c batch.hip -o ../build_$name/batch.o
 hipcc $FLAGS -c glue.hip -o ../build_$name/glue.o
-hipcc --offload-arch=gfx950 -shared -fPIC ../build/expand.o ../build/eager.o ../build_$name/batch.o ../build_$name/glue.o ../build/chipbatch.o ../build/abi_backend.o ../build/prover.o ../build/comm.o -ldl -o ../libh2w_$name.so
+hipcc $FLAGS -c expand.hip -o ../build_$name/expand.o
+hipcc --offload-arch=gfx950 -shared -fPIC ../build_$name/expand.o ../build/eager.o ../build_$name/batch.o ../build_$name/glue.o ../build/chipbatch.o ../build/abi_backend.o ../build/prover.o ../build/comm.o -ldl -o ../libh2w_$name.so
 echo "built $(realpath ../libh2w_$name.so)"
