@@ -185,7 +185,7 @@ struct h2w_plan {
     static constexpr int EV_RING = 64, N_EV = 9, N_SIDE = 16;
     hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 7 / 2 glue (+ Goldilocks Merkle strands) start / done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call, 8 expansion start
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
-    int serial_expand = -1;          // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's (-1: on with PoseidonBN254 caps)
+    int serial_expand = 1;           // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's
     bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
     explicit h2w_plan(int L) : tt(L) {}
@@ -464,9 +464,9 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
     // One expansion kernel at a time over all the streams a plan is driven on: its blocks are persistent and hold their CUs until the
     // launch is written, so two of them side by side keep the latency-bound strands of the other launches in flight off the chip
-    // (measured: +8..12 % for the whole job with PoseidonBN254 caps, profiles/r02_sweep5.txt; with Goldilocks caps, where the
-    // expansion kernel is the only bulk writer, overlapping its launches is better).
-    const bool serial = p->serial_expand < 0 ? p->shape.hash_mode == 1 : p->serial_expand != 0;
+    // (measured: +8..12 % for the whole job with PoseidonBN254 caps, profiles/r02_sweep5.txt; +5 % with Goldilocks caps since that kernel
+    // runs on a grid of resident blocks there and reaches its rate alone, profiles/r02_expand_grid.txt).
+    const bool serial = p->serial_expand != 0;
     if (serial && prev_ev && p->ev_recorded) H2W_HIP(hipStreamWaitEvent(estream, prev_ev[3], 0));
     H2W_HIP(hipEventRecord(ev[8], estream));
     if (!(dbg_skip & 4)) launch_expand(E, n_proofs, gx, estream);
@@ -782,7 +782,7 @@ int h2w_plan_event_gap(h2w_plan *p, uint64_t back_a, int which_a, uint64_t back_
 int h2w_plan_configure(h2w_plan *p, int option, int value) {
     if (!p) { set_error("h2w_plan_configure: null plan"); return -1; }
     if (option == H2W_OPT_FORK_CHAINS) { p->fork_chains = value != 0; return 0; }
-    if (option == H2W_OPT_SERIAL_EXPAND) { p->serial_expand = value < 0 ? -1 : value != 0; return 0; }
+    if (option == H2W_OPT_SERIAL_EXPAND) { p->serial_expand = value != 0; return 0; }      // (negative: the default, on)
     set_error("h2w_plan_configure: unknown option"); return -1;
 }
 

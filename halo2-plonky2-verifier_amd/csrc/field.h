@@ -155,30 +155,20 @@ HD fr_t fr_neg(const fr_t &a) { return fr_sub(fr_zero(), a); }
 #define H2W_R29_7 0x0e5c2634u
 #define H2W_R29_8 0x0030644eu
 constexpr int FR_MONT_BITS = 261;
-// The product in three pieces, so that a chain of dependent products can stay in limb form between them (coop.h, the partial rounds of the
-// PoseidonBN254 chain kernel): fr9_unpack (4 x 64 -> 9 x 29 bits), fr9_mul (limbs in, limbs out: a b / R mod r, NOT fully reduced: < 2 r when
-// the inputs are < 4 r - R = 2^261 leaves that slack), fr9_pack (9 x 29 -> canonical 4 x 64, one conditional subtraction).
-struct fr9_t { uint32_t t[9]; };
-HD fr9_t fr9_unpack(const fr_t &A) {
+HD fr_t fr_mont_mul(const fr_t &A, const fr_t &B, uint64_t ninv) {
     const uint32_t MASK = (1u << 29) - 1;
-    fr9_t a;
+    const uint32_t N[9] = {H2W_R29_0, H2W_R29_1, H2W_R29_2, H2W_R29_3, H2W_R29_4, H2W_R29_5, H2W_R29_6, H2W_R29_7, H2W_R29_8};
+    const uint32_t ninv29 = (uint32_t)ninv & MASK;            // -r^-1 mod 2^29
+    uint32_t a[9], b[9], m[9], t[9];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 0; j < 9; j++) {
         const int lo = 29 * j, w = lo >> 6, sh = lo & 63;
-        uint64_t xa = A.l[w] >> sh;
-        if (sh > 35 && w < 3) xa |= A.l[w + 1] << (64 - sh);
-        a.t[j] = (uint32_t)xa & MASK;
+        uint64_t xa = A.l[w] >> sh, xb = B.l[w] >> sh;
+        if (sh > 35 && w < 3) { xa |= A.l[w + 1] << (64 - sh); xb |= B.l[w + 1] << (64 - sh); }
+        a[j] = (uint32_t)xa & MASK; b[j] = (uint32_t)xb & MASK;
     }
-    return a;
-}
-HD fr9_t fr9_mul(const fr9_t &A, const fr9_t &B, uint64_t ninv) {
-    const uint32_t MASK = (1u << 29) - 1;
-    const uint32_t N[9] = {H2W_R29_0, H2W_R29_1, H2W_R29_2, H2W_R29_3, H2W_R29_4, H2W_R29_5, H2W_R29_6, H2W_R29_7, H2W_R29_8};
-    const uint32_t ninv29 = (uint32_t)ninv & MASK;            // -r^-1 mod 2^29
-    const uint32_t *a = A.t, *b = B.t;
-    uint32_t m[9]; fr9_t r;
     uint64_t acc = 0;
 #if defined(__HIPCC__)
 #pragma unroll
@@ -212,13 +202,9 @@ HD fr9_t fr9_mul(const fr9_t &A, const fr9_t &B, uint64_t ninv) {
 #endif
         for (int i = k - 8; i < 9; i++) { if (i & 1) acc += (uint64_t)m[i] * N[k - i]; else e += (uint64_t)m[i] * N[k - i]; }
         acc += e;
-        r.t[k - 9] = (uint32_t)acc & MASK; acc >>= 29;
+        t[k - 9] = (uint32_t)acc & MASK; acc >>= 29;
     }
-    r.t[8] = (uint32_t)acc;
-    return r;
-}
-HD fr_t fr9_pack(const fr9_t &T) {
-    const uint32_t *t = T.t;
+    t[8] = (uint32_t)acc;
     fr_t r;
     r.l[0] = (uint64_t)t[0] | ((uint64_t)t[1] << 29) | ((uint64_t)t[2] << 58);
     r.l[1] = ((uint64_t)t[2] >> 6) | ((uint64_t)t[3] << 23) | ((uint64_t)t[4] << 52);
@@ -227,7 +213,6 @@ HD fr_t fr9_pack(const fr9_t &T) {
     if (fr_geq_mod(r)) r = fr_sub_mod_raw(r);
     return r;
 }
-HD fr_t fr_mont_mul(const fr_t &A, const fr_t &B, uint64_t ninv) { return fr9_pack(fr9_mul(fr9_unpack(A), fr9_unpack(B), ninv)); }
 // canonical a*b mod r (two Montgomery products)
 HD fr_t fr_mul(const fr_t &a, const fr_t &b, const FrParams &P) {
     if ((a.l[1] | a.l[2] | a.l[3] | b.l[1] | b.l[2] | b.l[3]) == 0) return fr_from_u128((u128)a.l[0] * b.l[0]);

@@ -286,7 +286,7 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
  * runs on a library-owned side stream beside the query-glue and expansion kernels of the same call (they depend on the prologue
  * only); the caller's stream still completes when the whole advice is written.  0: every kernel on the caller's stream. */
 #define H2W_OPT_FORK_CHAINS 1
-/* H2W_OPT_SERIAL_EXPAND (default -1 = automatic: 1 with PoseidonBN254 caps, 0 with Goldilocks caps): the expansion kernel of a batch call
+/* H2W_OPT_SERIAL_EXPAND (default 1): the expansion kernel of a batch call
  * waits for the expansion kernel of the plan's previous batch call, whatever stream that was issued on, so that the latency-bound
  * strands of the other calls in flight find free CUs; the cells written are the same either way. */
 #define H2W_OPT_SERIAL_EXPAND 2

@@ -1,0 +1,68 @@
+"""Code-generation invariants of the two hot kernels, checked on the cross-compiled gfx950 assembly (no GPU needed).
+
+On this family loads and stores retire in order on one counter (vmcnt): a scratch or flat access inside a round loop makes the wavefront
+wait for every cell store it has in flight.  Twice in round 2 a source change that "did not touch the arithmetic" (a struct select, a
+refactoring of the Montgomery product into helper functions) put spill reloads into the PoseidonBN254 partial-round loop and cost 3-8 % of the
+chain kernel; this test is the guard."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "halo2-plonky2-verifier_amd", "csrc")
+FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -Wno-unused-value -x hip -S --cuda-device-only".split()
+
+
+def _asm(src, tmp_path):
+    if not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    out = os.path.join(str(tmp_path), src + ".s")
+    subprocess.run(["hipcc", *FLAGS, os.path.join(CSRC, src), "-o", out], check=True, capture_output=True, cwd=CSRC)
+    return open(out).read().split("\n")
+
+
+def _function(lines, mangled_prefix):
+    start = next(i for i, l in enumerate(lines) if re.match("^" + re.escape(mangled_prefix) + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if "s_setpc_b64" in lines[i] or "s_endpgm" in lines[i])
+    return start, end
+
+
+def _loops(lines, lo, hi):
+    """(first, last) line of every natural loop = backward branch to a label inside [lo, hi)."""
+    labels = {m.group(1): i for i in range(lo, hi) for m in [re.match(r"^(\.LBB\d+_\d+):", lines[i])] if m}
+    for i in range(lo, hi):
+        m = re.search(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", lines[i])
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            yield labels[m.group(1)], i
+
+
+def _count(lines, a, b, pat):
+    return sum(1 for l in lines[a:b + 1] if re.match(r"^\s+" + pat, l))
+
+
+def test_chain_round_loops_have_no_scratch_or_flat_accesses(tmp_path):
+    lines = _asm("batch.hip", tmp_path)
+    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0EE14bn_emit_inline")       # the flat-layout emitter of k_merkle_bn_quad
+    loops = list(_loops(lines, lo, hi))
+    partial = [(a, b) for a, b in loops if 780 <= _count(lines, a, b, "v_mad_u64_u32") <= 830]
+    assert partial, "partial-round loop (five products, 805 multiply-adds) not found"
+    a, b = min(partial, key=lambda ab: ab[1] - ab[0])
+    bad = _count(lines, a, b, "scratch_") + _count(lines, a, b, "flat_")
+    assert bad == 0, f"{bad} scratch/flat accesses in the partial-round loop (asm lines {a}-{b})"
+    n = sum(1 for l in lines[a:b + 1] if re.match(r"^\s+[a-z]", l))
+    assert n <= 2200, f"partial round grew to {n} instructions"
+    # the full-round loop: x^5 (five products) around the rolled four-product mix loop
+    full = [(c, d) for c, d in loops if (d < a or c > b) and 700 <= _count(lines, c, d, "v_mad_u64_u32") <= 1100]
+    assert full, "full-round loop not found"
+    for c, d in full:
+        assert _count(lines, c, d, "scratch_") + _count(lines, c, d, "flat_") == 0, f"scratch/flat accesses in the full-round loop (asm lines {c}-{d})"
+
+
+def test_expand_fast_has_no_scratch(tmp_path):
+    lines = _asm("expand.hip", tmp_path)
+    lo, hi = _function(lines, "_ZN3h2w11expand_fastILi21EE")
+    assert _count(lines, lo, hi, "scratch_") == 0
+    assert _count(lines, lo, hi, "flat_store") == 0      # every cell store is a global_store
