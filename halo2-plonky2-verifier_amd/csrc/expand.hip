@@ -232,7 +232,7 @@ template <int L> constexpr bool fast_is_neg(int v) {        // virtual cells hol
 }
 constexpr int FAST_CH = 8;                                  // virtual cells per flush step (256 B per record and store instruction)
 constexpr int FAST_T = 16;                                  // records per pass of a wavefront
-template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
+template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
     typedef FastMap<L> M;
     constexpr int NCH = (M::VT + FAST_CH - 1) / FAST_CH;
     constexpr int ROW = M::VT * 16 + 16;                      // bytes per record row of the LDS tile: the low halves of its virtual cells (+ padding); the last step's lanes past VT never read
@@ -244,7 +244,7 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
     // start spread over the proofs and move on to the next proof that has tiles left.  With more blocks than fit, the late ones start when
     // the first proofs are done and ramp up again: 5.5-5.8 TB/s for a launch alone against 6.3 with every block resident from the start
     // (profiles/r02_expand_grid.txt).
-    uint64_t proof = A.roam ? (uint64_t)((blockIdx.x * (EXPAND_THREADS / 64) + wv) % A.nproofs) : (uint64_t)blockIdx.y;
+    uint64_t proof = ROAM ? (uint64_t)((blockIdx.x * (EXPAND_THREADS / 64) + wv) % A.nproofs) : (uint64_t)blockIdx.y;
     const uint32_t ntiles = (uint32_t)((A.nrec + 63) / 64);
     // -2^RB mod r (the one 254-bit constant of check_less_than): limbs of r with bit RB taken out of limb 1 (no borrow)
     const ull neg0 = H2W_FR_M0, neg1 = H2W_FR_M1 - (1ull << (M::RB - 64)), neg2 = H2W_FR_M2, neg3 = H2W_FR_M3;
@@ -354,7 +354,7 @@ template <int L> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fas
         }
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
     }
-    if (!A.roam) break;
+    if (!ROAM) break;
     // the next proof (cyclically) whose counter says tiles are left: 64 counters per look.  A stale or racing read only costs a visit.
     int nx = -1;
     for (uint32_t base = 0; base < A.nproofs && nx < 0; base += 64) {
@@ -394,9 +394,15 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
             if (nb < 1) nb = 1;
             B.roam = 1; grid = dim3((unsigned)nb, 1);
         }
-        if (A.lookup_bits == 21) hipLaunchKernelGGL(expand_fast<21>, grid, dim3(EXPAND_THREADS), 0, stream, B);
-        else if (A.lookup_bits == 13) hipLaunchKernelGGL(expand_fast<13>, grid, dim3(EXPAND_THREADS), 0, stream, B);
-        else hipLaunchKernelGGL(expand_fast<8>, grid, dim3(EXPAND_THREADS), 0, stream, B);
+        if (B.roam) {
+            if (A.lookup_bits == 21) hipLaunchKernelGGL((expand_fast<21, true>), grid, dim3(EXPAND_THREADS), 0, stream, B);
+            else if (A.lookup_bits == 13) hipLaunchKernelGGL((expand_fast<13, true>), grid, dim3(EXPAND_THREADS), 0, stream, B);
+            else hipLaunchKernelGGL((expand_fast<8, true>), grid, dim3(EXPAND_THREADS), 0, stream, B);
+        } else {
+            if (A.lookup_bits == 21) hipLaunchKernelGGL((expand_fast<21, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
+            else if (A.lookup_bits == 13) hipLaunchKernelGGL((expand_fast<13, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
+            else hipLaunchKernelGGL((expand_fast<8, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
+        }
         return;
     }
     const int TILE_RECS = 32;
