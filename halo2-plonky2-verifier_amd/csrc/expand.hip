@@ -383,6 +383,8 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
         bool roam_ok = A.allow_roam && ntiles >= 64 && nproofs <= 4096 && grid_x > 0;
 #ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/build_debug_variant.sh)
         { static int no = -1; if (no < 0) { const char *e = getenv("H2W_DBG_NO_ROAM"); no = e ? atoi(e) : 0; } if (no) roam_ok = false; }
+        static int dbg_nb = -1; if (dbg_nb < 0) { const char *e = getenv("H2W_DBG_ROAM_BLOCKS"); dbg_nb = e ? atoi(e) : 0; }      // > 0: roam with that many blocks, whatever the caller allows
+        if (dbg_nb > 0) roam_ok = ntiles >= 64 && nproofs <= 4096;
 #endif
         if (roam_ok) {
             static int cus[64] = {0}; int dev = 0; (void)hipGetDevice(&dev);
@@ -392,6 +394,9 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
             uint64_t nb = (uint64_t)ncu * per_cu;
             const uint64_t want = (ntiles * nproofs + waves - 1) / waves; if (nb > want) nb = want;
             if (nb < 1) nb = 1;
+#ifdef H2W_DEBUG_HOOKS
+            if (dbg_nb > 0) nb = (uint64_t)dbg_nb;
+#endif
             B.roam = 1; grid = dim3((unsigned)nb, 1);
         }
         if (B.roam) {
