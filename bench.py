@@ -322,7 +322,7 @@ def main():
         kbytes = {"expand": B * plan.num_record_cells * 32 * share}
         if hash_mode == 1:
             kbytes["merkle_chains"] = B * plan.num_chain_cells * 32 * share
-        names = {"expand": "expand_fast<%d, %s>" % (args.lookup_bits, "true" if hash_mode == 0 else "false") if args.lookup_bits in (21, 13, 8) else "expand_kernel_t", "merkle_chains": "k_merkle_bn_quad",
+        names = {"expand": "expand_fast<%d, true>" % args.lookup_bits if args.lookup_bits in (21, 13, 8) else "expand_kernel_t", "merkle_chains": "k_merkle_bn_quad",
                  "prologue": "k_prologue_coop", "glue_strands": "k_strands", "glue_and_merkle_strands": "k_strands + k_merkle_gl_coop"}
         kernels = {}
         dom, achieved = "expand", None

@@ -455,7 +455,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
     p->dt.fill(E);
     E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
-    E.allow_roam = p->shape.hash_mode == 0;      // (with PoseidonBN254 caps the chain kernels of the launches in flight take their CUs as blocks of the expansion kernel exit: profiles/r02_expand_grid.txt)
+    E.roam_per_cu = p->shape.hash_mode == 0 ? 2 : 1;      // (profiles/r02_expand_grid.txt)
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
 #ifdef H2W_DEBUG_HOOKS
     { static int dgx = -1; if (dgx < 0) { const char *e = getenv("H2W_DBG_EXPAND_GX"); dgx = e ? atoi(e) : 0; } if (dgx > 0) gx = dgx; }
@@ -496,7 +496,7 @@ int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, voi
     if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
     p->dt.fill(E);
     E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
-    E.allow_roam = p->shape.hash_mode == 0;      // (with PoseidonBN254 caps the chain kernels of the launches in flight take their CUs as blocks of the expansion kernel exit: profiles/r02_expand_grid.txt)
+    E.roam_per_cu = p->shape.hash_mode == 0 ? 2 : 1;      // (profiles/r02_expand_grid.txt)
     H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), stream));
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
     launch_expand(E, n_proofs, gx, stream);

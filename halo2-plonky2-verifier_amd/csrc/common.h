@@ -56,7 +56,8 @@ struct ExpandArgs {
     uint32_t max_cells;        // largest template (cells per record) of the plan: sizes expand_kernel_h's chunk table
     uint32_t *tile_ctr;        // [nproofs] zeroed work counters: tiles are handed out dynamically (null: static striding)
     uint32_t nproofs, roam;    // expand_fast: roam != 0 -> a 1-D grid of resident blocks whose wavefronts move on to the next proof with tiles left (set by launch_expand)
-    uint32_t allow_roam = 0;   // caller: this launch has the chip to itself as far as LDS goes (no PoseidonBN254 chain kernel beside it, whose blocks get their CUs when blocks of this kernel exit)
+    uint32_t roam_per_cu = 0;  // caller: 0 = one grid column of blocks per proof; k > 0 = roaming wavefronts on (at most) k blocks per CU.  2 fills the
+                               // chip (Goldilocks caps: nothing else needs LDS); 1 leaves half of every CU's LDS to the PoseidonBN254 chain kernels of the launches in flight
     ColMap cm;                 // column-major emission (starts == nullptr: flat)
     // (proof, query) sharding: records of query blocks owned by another rank are skipped (shard_world <= 1: none)
     uint64_t q_rec0_first, q_rec0_rest, q_nrec_rest; uint32_t nq, shard_rank, shard_world;

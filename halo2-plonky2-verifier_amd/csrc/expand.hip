@@ -380,7 +380,7 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
         dim3 grid((unsigned)gx, (unsigned)nproofs);
         // roaming wavefronts: a batch of proofs with many tiles each (the witness path); many small instances (h2w_chipbatch) keep one column each
         const uint64_t waves = EXPAND_THREADS / 64;
-        bool roam_ok = A.allow_roam && ntiles >= 64 && nproofs <= 4096 && grid_x > 0;
+        bool roam_ok = A.roam_per_cu > 0 && ntiles >= 64 && nproofs <= 4096 && grid_x > 0;
 #ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/build_debug_variant.sh)
         { static int no = -1; if (no < 0) { const char *e = getenv("H2W_DBG_NO_ROAM"); no = e ? atoi(e) : 0; } if (no) roam_ok = false; }
         static int dbg_nb = -1; if (dbg_nb < 0) { const char *e = getenv("H2W_DBG_ROAM_BLOCKS"); dbg_nb = e ? atoi(e) : 0; }      // > 0: roam with that many blocks, whatever the caller allows
@@ -390,7 +390,8 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
             static int cus[64] = {0}; int dev = 0; (void)hipGetDevice(&dev);
             if (dev >= 0 && dev < 64 && !cus[dev]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = n > 0 ? n : 256; }
             const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
-            const int per_cu = A.lookup_bits == 21 ? 2 : 1;                      // blocks of this kernel one CU holds (LDS)
+            int per_cu = A.lookup_bits == 21 ? 2 : 1;                            // blocks of this kernel one CU holds (LDS)
+            if (A.roam_per_cu > 0 && (int)A.roam_per_cu < per_cu) per_cu = (int)A.roam_per_cu;
             uint64_t nb = (uint64_t)ncu * per_cu;
             const uint64_t want = (ntiles * nproofs + waves - 1) / waves; if (nb > want) nb = want;
             if (nb < 1) nb = 1;
