@@ -231,7 +231,10 @@ template <int L> constexpr bool fast_is_neg(int v) {        // virtual cells hol
     return v == 5 + 1 + FastMap<L>::RC + 4 || v == 5 + FastMap<L>::LW + 1 + FastMap<L>::RC + 4;
 }
 constexpr int FAST_CH = 8;                                  // virtual cells per flush step (256 B per record and store instruction)
-constexpr int FAST_T = 16;                                  // records per pass of a wavefront
+#ifndef H2W_FAST_T
+#define H2W_FAST_T 16
+#endif
+constexpr int FAST_T = H2W_FAST_T;                          // records per pass of a wavefront (LDS per block scales with it: 73 KB at 16)
 template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
     typedef FastMap<L> M;
     constexpr int NCH = (M::VT + FAST_CH - 1) / FAST_CH;
@@ -390,7 +393,7 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
             static int cus[64] = {0}; int dev = 0; (void)hipGetDevice(&dev);
             if (dev >= 0 && dev < 64 && !cus[dev]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = n > 0 ? n : 256; }
             const int ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
-            int per_cu = A.lookup_bits == 21 ? 2 : 1;                            // blocks of this kernel one CU holds (LDS)
+            int per_cu = A.lookup_bits == 21 ? (FAST_T <= 8 ? 4 : 2) : 1;        // blocks of this kernel one CU holds (LDS)
             if (A.roam_per_cu > 0 && (int)A.roam_per_cu < per_cu) per_cu = (int)A.roam_per_cu;
             uint64_t nb = (uint64_t)ncu * per_cu;
             const uint64_t want = (ntiles * nproofs + waves - 1) / waves; if (nb > want) nb = want;
