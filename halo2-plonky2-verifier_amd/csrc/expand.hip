@@ -234,6 +234,10 @@ constexpr int FAST_CH = 8;                                  // virtual cells per
 #ifndef H2W_FAST_T
 #define H2W_FAST_T 16
 #endif
+#ifndef H2W_FAST_K
+#define H2W_FAST_K 4
+#endif
+constexpr int FAST_K = H2W_FAST_K;                          // 64-record rows per fetch of a wavefront (its work unit: 256 records)
 constexpr int FAST_T = H2W_FAST_T;                          // records per pass of a wavefront (LDS per block scales with it: 73 KB at 16)
 template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
     typedef FastMap<L> M;
@@ -248,7 +252,7 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
     // the first proofs are done and ramp up again: 5.5-5.8 TB/s for a launch alone against 6.3 with every block resident from the start
     // (profiles/r02_expand_grid.txt).
     uint64_t proof = ROAM ? (uint64_t)((blockIdx.x * (EXPAND_THREADS / 64) + wv) % A.nproofs) : (uint64_t)blockIdx.y;
-    const uint32_t ntiles = (uint32_t)((A.nrec + 63) / 64);
+    const uint32_t ntiles = (uint32_t)((A.nrec + 64 * FAST_K - 1) / (64 * FAST_K));      // work units a wavefront takes from its proof's counter
     // -2^RB mod r (the one 254-bit constant of check_less_than): limbs of r with bit RB taken out of limb 1 (no borrow)
     const ull neg0 = H2W_FR_M0, neg1 = H2W_FR_M1 - (1ull << (M::RB - 64)), neg2 = H2W_FR_M2, neg3 = H2W_FR_M3;
     unsigned char *my_row = &s_tile[wv][(lane & (FAST_T - 1)) * ROW];
@@ -267,10 +271,30 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
     { uint32_t t0 = 0; if (lane == 0) t0 = atomicAdd(&A.tile_ctr[proof], 1u); tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0); }
     while (tile < ntiles) {
         uint32_t nxt = 0; if (lane == 0) nxt = atomicAdd(&A.tile_ctr[proof], 1u);       // next tile: requested now, read at the bottom
+        // The records of FAST_K * 64 consecutive records in one fetch, one record (+ meta) per lane and 64-record row; the passes take theirs
+        // from those registers with cross-lane reads.  Loads and stores retire in order on this family, so every vector load a wavefront
+        // consumes costs it a wait for all the cell stores it has in flight: one such wait per 16 passes instead of one per pass
+        // (profiles/r02_expand_grid.txt: a timing build without the per-pass loads ran the whole job 9 % faster).
+        const uint64_t sbase = (uint64_t)tile * (64 * FAST_K);
+        uint64_t mk[FAST_K]; rec_t rk[FAST_K];
+#pragma unroll
+        for (int j = 0; j < FAST_K; j++) {
+            const uint64_t r = sbase + (uint64_t)j * 64 + (uint64_t)lane;
+            mk[j] = 0; rk[j].a = rk[j].b = rk[j].c = rk[j].d = 0;
+            if (r < A.nrec) { mk[j] = A.meta[r]; rk[j] = recs[r]; }
+        }
 #pragma unroll 1
-        for (int pass = 0; pass < 64 / FAST_T; pass++) {
-            const uint64_t r0 = (uint64_t)tile * 64 + (uint64_t)pass * FAST_T;
+        for (int pass = 0; pass < FAST_K * (64 / FAST_T); pass++) {
+            const int fj = pass / (64 / FAST_T), fq = pass % (64 / FAST_T);
+            const uint64_t r0 = sbase + (uint64_t)fj * 64 + (uint64_t)fq * FAST_T;
             if (r0 >= A.nrec) break;
+            uint64_t cm = mk[0]; rec_t cr = rk[0];
+#pragma unroll
+            for (int j = 1; j < FAST_K; j++) if (fj == j) { cm = mk[j]; cr.a = rk[j].a; cr.b = rk[j].b; cr.c = rk[j].c; cr.d = rk[j].d; }      // (wave-uniform selects)
+            const int src = fq * FAST_T + (lane & (FAST_T - 1));
+            const uint64_t pm = __shfl((unsigned long long)cm, src, 64);
+            rec_t prc; prc.a = __shfl((unsigned long long)cr.a, src, 64); prc.b = __shfl((unsigned long long)cr.b, src, 64);
+            prc.c = __shfl((unsigned long long)cr.c, src, 64); prc.d = __shfl((unsigned long long)cr.d, src, 64);
             bool mine = lane < FAST_T && r0 + (uint64_t)lane < A.nrec;
             if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block belongs to rank proof mod world
                 const uint64_t r = r0 + lane;
@@ -280,7 +304,7 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
                 } else mine = proof % A.shard_world == A.shard_rank;      // prologue block: the proof's owner
             }
             uint32_t t = T_LITERAL; rec_t rc; rc.a = rc.b = rc.c = rc.d = 0; ull coff = 0;
-            if (mine) { const uint64_t m = A.meta[r0 + lane]; rc = recs[r0 + lane]; t = meta_tmpl(m); coff = meta_off(m); }
+            if (mine) { rc = prc; t = meta_tmpl(pm); coff = meta_off(pm); }
             // template -> range of virtual cells
             int vs = 0, ve = 0; FastBases b; b.pre = 0;
             const bool glop = t == T_GLOP || t == T_KA_GLOP || t == T_KB_GLOP;
@@ -377,17 +401,17 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
     if (A.nrec == 0 || nproofs == 0) return;
     const bool fast_ok = A.tile_ctr != nullptr && A.pool == nullptr && A.cm.starts == nullptr && A.ntmpl <= T_DYNAMIC;
     if (fast_ok && (A.lookup_bits == 21 || A.lookup_bits == 13 || A.lookup_bits == 8)) {
-        const uint64_t ntiles = (A.nrec + 63) / 64;
+        const uint64_t ntiles = (A.nrec + 64 * FAST_K - 1) / (64 * FAST_K);
         uint64_t gx = (uint64_t)grid_x; if (gx * (EXPAND_THREADS / 64) > ntiles) gx = (ntiles + EXPAND_THREADS / 64 - 1) / (EXPAND_THREADS / 64); if (gx < 1) gx = 1;
         ExpandArgs B = A; B.nproofs = (uint32_t)nproofs; B.roam = 0;
         dim3 grid((unsigned)gx, (unsigned)nproofs);
         // roaming wavefronts: a batch of proofs with many tiles each (the witness path); many small instances (h2w_chipbatch) keep one column each
         const uint64_t waves = EXPAND_THREADS / 64;
-        bool roam_ok = A.roam_per_cu > 0 && ntiles >= 64 && nproofs <= 4096 && grid_x > 0;
+        bool roam_ok = A.roam_per_cu > 0 && ntiles >= 16 && nproofs <= 4096 && grid_x > 0;
 #ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/build_debug_variant.sh)
         { static int no = -1; if (no < 0) { const char *e = getenv("H2W_DBG_NO_ROAM"); no = e ? atoi(e) : 0; } if (no) roam_ok = false; }
         static int dbg_nb = -1; if (dbg_nb < 0) { const char *e = getenv("H2W_DBG_ROAM_BLOCKS"); dbg_nb = e ? atoi(e) : 0; }      // > 0: roam with that many blocks, whatever the caller allows
-        if (dbg_nb > 0) roam_ok = ntiles >= 64 && nproofs <= 4096;
+        if (dbg_nb > 0) roam_ok = ntiles >= 16 && nproofs <= 4096;
 #endif
         if (roam_ok) {
             static int cus[64] = {0}; int dev = 0; (void)hipGetDevice(&dev);
