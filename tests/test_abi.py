@@ -124,3 +124,11 @@ def test_comm_entry_points_fail_loudly_without_a_device(h2w):
     assert not L.h2w_comm_init(ident, 0, 1, 0) and "no HIP device" in h2w.last_error()
     assert L.h2w_comm_rank(None) == -1 and L.h2w_comm_world(None) == 0
     L.h2w_comm_free(None)
+
+
+def test_product_library_has_no_experiment_switches(h2w):
+    """The timing-experiment switches (H2W_DBG_* environment variables, tools/build_debug_variant.sh) exist only under -DH2W_DEBUG_HOOKS:
+    the library the tests, smoke() and bench.py load contains none of them (round 1 shipped wrong-output kernel variants behind getenv)."""
+    blob = open(h2w.LIB_PATH, "rb").read()
+    assert b"H2W_DBG" not in blob and b"H2W_EXPAND_VARIANT" not in blob and b"H2W_BN_UNITS" not in blob
+    assert os.path.basename(h2w.LIB_PATH) == "libh2w.so" or os.environ.get("H2W_LIB")
