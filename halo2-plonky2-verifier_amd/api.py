@@ -301,6 +301,22 @@ class Plan:
         """This rank's (proof, query) units of the batch (h2w_fri_witness_batch_shard)."""
         _ck(self.L.h2w_fri_witness_batch_shard(self.p, proofs_ptr, n, advice_ptr, workspace_ptr, stream, rank, world), "h2w_fri_witness_batch_shard")
 
+    def run_shard_compact(self, proofs_ptr, n, shard_advice_ptr, workspace_ptr, rank, world, stream=0):
+        """The same blocks packed into a buffer of shard_cells(n, rank, world) cells (h2w_fri_witness_batch_shard_compact)."""
+        _ck(self.L.h2w_fri_witness_batch_shard_compact(self.p, proofs_ptr, n, shard_advice_ptr, workspace_ptr, stream, rank, world), "h2w_fri_witness_batch_shard_compact")
+
+    def shard_cells(self, n, rank, world):
+        return int(self.L.h2w_plan_shard_cells(self.p, n, rank, world))
+
+    def shard_block(self, rank, world, proof, query):
+        """(local cell, cells, global cell) of a block in rank's packed buffer; None when another rank owns it.  query < 0: the prologue block."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = self.L.h2w_plan_shard_block(self.p, rank, world, proof, query, C.byref(a), C.byref(b), C.byref(c))
+        if rc == 1:
+            return None
+        _ck(rc, "h2w_plan_shard_block")
+        return int(a.value), int(b.value), int(c.value)
+
     def run_columns(self, proofs_ptr, n, break_points, k, columns_ptr, workspace_ptr, stream=0):
         """Batched hot path writing the FlexGate column layout directly (h2w_fri_witness_batch_columns)."""
         bp = (C.c_uint64 * max(len(break_points), 1))(*break_points)
@@ -342,6 +358,12 @@ class Plan:
         ms = (C.c_float * 5)()
         _ck(self.L.h2w_plan_timing(self.p, back, ms), "h2w_plan_timing")
         return tuple(ms)
+
+    def timing_ex(self, back=0):
+        """Per kernel, ms: (prologue values, permutation records, glue strands, chain values, chain emission, expansion, whole call)."""
+        ms = (C.c_float * 8)()
+        _ck(self.L.h2w_plan_timing_ex(self.p, back, ms), "h2w_plan_timing_ex")
+        return tuple(float(x) for x in ms)[:7]
 
     def last_timing(self):
         ms = (C.c_float * 5)()

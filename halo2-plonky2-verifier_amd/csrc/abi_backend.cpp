@@ -16,7 +16,7 @@ namespace h2w {
 
 struct AbiBackend {
     typedef h2w_assigned_t Gl; typedef h2w_assigned_t Bool; typedef h2w_assigned_t Fr; typedef h2w_assigned_t Big;
-    static constexpr bool kCoopPoseidon = false, kSplitOnly = false;
+    static constexpr bool kCoopPoseidon = false, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = -1;
     h2w_ctx *ctx; int mode; const uint64_t *proof; std::vector<h2w_assigned_t> wires; uint32_t status = 0; int rc = 0;
     AbiBackend(h2w_ctx *c, int hash_mode, const uint64_t *proof_words, size_t n_words) : ctx(c), mode(hash_mode), proof(proof_words), wires(n_words) {}
     void ck(int r) { if (r != 0 && rc == 0) rc = r; }
@@ -26,6 +26,7 @@ struct AbiBackend {
     uint64_t gl_val(const Gl &w) { return w.value.l[0]; }
     Gl bool_as_gl(const Bool &b) { return b; }
     void coop_poseidon_permute(Gl *, const h2w_poseidon_consts_t *) {}
+    void glp_note() {}
     // ---- Goldilocks level (h2w_gl_*)
     Gl gl_const(uint64_t k) { Gl o; ck(h2w_gl_load_constant(ctx, k, &o)); return o; }
     void gl_const_run(uint64_t k, int n, Gl *out) { for (int i = 0; i < n; i++) out[i] = gl_const(k); }
@@ -68,7 +69,10 @@ struct AbiBackend {
     Fr fr_mul(const Fr &a, const Fr &b) { Fr o; ck(h2w_mul(ctx, &a, &b, &o)); return o; }
     Fr fr_mul_add(const Fr &a, const Fr &b, const Fr &c) { Fr o; ck(h2w_mul_add(ctx, &a, &b, &c, &o)); return o; }
     Fr fr_select(const Fr &a, const Fr &b, const Bool &sel) { Fr o; ck(h2w_select(ctx, &a, &b, &sel, &o)); return o; }
-    Fr fr_select_from_idx(const Fr *col, int n, const Gl &idx) { Fr o; ck(h2w_select_from_idx(ctx, col, (size_t)n, &idx, &o)); return o; }
+    template <class ColF> Fr fr_select_from_idx_fn(int n, ColF colf, const Gl &idx) {
+        std::vector<Fr> col((size_t)n); for (int i = 0; i < n; i++) col[i] = colf(i);
+        Fr o; ck(h2w_select_from_idx(ctx, col.data(), (size_t)n, &idx, &o)); return o;
+    }
     Fr limbs_to_num(const Gl *in, int n) { Fr o; ck(h2w_limbs_to_num(ctx, in, (size_t)n, 64, &o)); return o; }
     void decompose_le_56_5(const Fr &x, Gl *out) { ck(h2w_decompose_le(ctx, &x, 56, 5, out)); }
     // ---- proof wires
@@ -154,6 +158,10 @@ int h2w_chip_two_to_one(h2w_ctx *ctx, const h2w_poseidon_consts_t *k, int hash_m
 // MerkleTreeChip::verify_proof_to_cap_with_cap_index (merkle/mod.rs:57-78); hash wires: 4 (mode 0) or 1 (mode 1) assigned values each
 int h2w_chip_merkle_verify(h2w_ctx *ctx, const h2w_poseidon_consts_t *k, int hash_mode, const Av *leaf, size_t n_leaf, const Av *bits, size_t n_bits,
                            const Av *cap_index, const Av *cap, size_t n_cap, const Av *siblings, size_t n_sib) {
+    if (!ctx || !k || !leaf || !bits || !cap_index || !cap || (!siblings && n_sib)) { set_error("h2w_chip_merkle_verify: null argument"); return -1; }
+    if (hash_mode < 0 || hash_mode > 1 || n_leaf < 1 || n_cap < 1 || n_cap > (size_t)MAX_CAP || n_bits > 64 || n_sib > 64) {
+        set_error("h2w_chip_merkle_verify: out of range (hash_mode 0/1, 1 <= n_cap <= 64, n_bits <= 64, n_sib <= 64, n_leaf >= 1)"); return -1;
+    }
     AbiBackend be(ctx, hash_mode, nullptr, 0); MerkleTreeChip<AbiBackend> mk(be, hash_mode, k);
     const int hw = hash_mode == 0 ? 4 : 1;
     mk.verify_proof_to_cap_with_cap_index(leaf, (int)n_leaf, bits, (int)n_bits, *cap_index, (int)n_cap,
@@ -165,6 +173,7 @@ int h2w_chip_merkle_verify(h2w_ctx *ctx, const h2w_poseidon_consts_t *k, int has
 // StarkChip::verify_proof (stark/mod.rs:483-508)
 int h2w_chip_verify_stark(h2w_ctx *ctx, const h2w_shape_t *shape, const h2w_poseidon_consts_t *k, const uint64_t *proof_words) {
     if (!ctx || !shape || !k || !proof_words) { set_error("h2w_chip_verify_stark: null argument"); return -1; }
+    if (const char *why = shape_check(*shape)) { set_error(std::string("h2w_chip_verify_stark: unsupported shape: ") + why); return -1; }
     Derived d = derive_shape(*shape); ProofLayout pl = proof_layout(*shape, d);
     AbiBackend be(ctx, shape->hash_mode, proof_words, pl.total);
     Verifier<AbiBackend> V(be, *shape, k);

@@ -2,12 +2,18 @@
 //
 //   h2w_plan_compile : shape compiler.  Replays the gadget once on the host with a counting sink
 //                      (ValBackend<PlanSink>) to fix the offset of every cell block and strand for this shape.
-//   h2w_fri_witness_batch : per batch, three HIP launches on the caller's stream
-//        k_prologue  one lane per proof      : witness load, Fiat-Shamir challenger (serial sponge), PoW, reduced openings
-//        k_strands   one lane per (proof, query[, merkle tree]) : FRI query glue and Merkle paths (value domain)
-//        expand      one lane per advice cell: the HBM-write-bound materialisation (expand.hip)
-// Data layout in HBM (per batch): proofs [n][proof_words] u64 ; records [n][n_records] 32 B ; challenge blocks [n] ;
-// advice [n][n_cells] 32 B canonical-LE Fr.  Record metas / templates / Poseidon constants are per-shape and shared.
+//   h2w_fri_witness_batch : per batch, on the caller's stream (+ one side stream of the plan)
+//        k_prologue_values  one wavefront per proof : witness load, Fiat-Shamir challenger ON VALUES (serial sponge), PoW, reduced
+//                           openings -> challenge block, the prologue's direct cells / non-permutation records, the permutation list
+//        k_glp_emit         one wavefront per listed Goldilocks-Poseidon permutation -> its 2,604 block records
+//        k_strands          one lane per (proof, query) : FRI query glue (glue.hip) -> records
+//        PoseidonBN254 caps : k_merkle_bn_values  one quad per (proof, query, tree): the Merkle path ON VALUES -> unit states
+//                             k_merkle_bn_emit    one quad per permutation unit of every path: its cells, straight to the advice
+//        Goldilocks caps    : k_merkle_gl_values  one wavefront per (proof, query, tree) -> select records, the permutation list
+//        expand_fast        block records -> cells: the HBM-write-bound materialisation (expand.hip)
+// Data layout in HBM (per batch): proofs [n][proof_words] u64 ; records [n][n_records] 32 B ; challenge blocks [n] ; unit states
+// [n][units][4] 32 B ; permutation list [n][perms][13] u64 ; advice [n][n_cells] 32 B canonical-LE Fr.  Record metas / templates /
+// Poseidon constants are per-shape and shared.
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <string>
@@ -23,11 +29,12 @@ namespace h2w {
 
 
 struct PlanSink {
-    static constexpr bool kCoop = false, kSplitOnly = false;
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = -1;
     void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     std::vector<uint64_t> *meta; const TemplateTable *tt; StrandTable *st;
     uint64_t nrec = 0, cell_off = 0, cur_q_rec = 0, cur_q_cell = 0, mk_rec0 = 0, mk_cell0 = 0; bool mk_zc = false;
     std::vector<uint64_t> *unit_cell = nullptr; uint64_t nunit = 0, cur_q_unit = 0, mk_unit0 = 0; bool pu_zc = false;
+    uint64_t nglp = 0, cur_q_glp = 0, mk_glp0 = 0; int cur_q = -1;
     std::vector<LoadItem> *items = nullptr;
     void note_load(uint64_t w, int kind) { LoadItem it; it.word = (uint32_t)w; it.kind = (uint32_t)kind; it.rec = nrec; it.cell = cell_off; items->push_back(it); }
     bool coop_load_proof(const ValCfg &) { return false; }
@@ -39,6 +46,7 @@ struct PlanSink {
     void end_lane_cells(uint64_t) {}
     void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
     void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
+    void glp_note() { nglp++; }
     // keygen metadata pass (h2w_plan_metadata): one bit per cell, set from the template slot flags / the backend's G()/LK() markers
     std::vector<uint8_t> *sel_bits = nullptr, *lk_bits = nullptr; uint8_t pend = 0;
     void mark(uint64_t cell, uint8_t f) {
@@ -54,102 +62,140 @@ struct PlanSink {
     }
     void cell(const fr_t &) { if (sel_bits && pend) mark(cell_off, pend); pend = 0; cell_off++; }
     void skip(uint64_t, uint64_t) {}
-    void merkle_begin(int, int, bool zc, uint64_t) { mk_rec0 = nrec; mk_cell0 = cell_off; mk_zc = zc; mk_unit0 = nunit; }
+    void merkle_begin(int, int, bool zc, uint64_t) { mk_rec0 = nrec; mk_cell0 = cell_off; mk_zc = zc; mk_unit0 = nunit; mk_glp0 = nglp; }
     void merkle_end(int q, int kind, bool zc) {
         if (q > 1) return;
         st->mk_rec_rel[q][kind] = mk_rec0 - cur_q_rec; st->mk_cell_rel[q][kind] = mk_cell0 - cur_q_cell;
         st->mk_nrec[q][kind] = nrec - mk_rec0; st->mk_ncell[q][kind] = cell_off - mk_cell0; st->mk_unit_rel[q][kind] = mk_unit0 - cur_q_unit;
+        st->mk_nunit[kind] = (uint32_t)(nunit - mk_unit0); st->mk_glp_rel[kind] = (uint32_t)(mk_glp0 - cur_q_glp); st->mk_nglp[kind] = (uint32_t)(nglp - mk_glp0);
         if (!mk_zc && zc) st->first_zero_kind = (q == 0) ? kind : -2;
     }
-    void query_begin(int q, uint64_t) { cur_q_rec = nrec; cur_q_cell = cell_off; cur_q_unit = nunit; if (q <= 1) { st->q_rec0[q] = nrec; st->q_cell0[q] = cell_off; st->q_unit0[q] = nunit; } }
-    void query_end(int q, uint64_t) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; st->q_nunit[q] = nunit - cur_q_unit; } }
+    void query_begin(int q, uint64_t) {
+        cur_q_rec = nrec; cur_q_cell = cell_off; cur_q_unit = nunit; cur_q_glp = nglp;
+        if (q == 0) st->pro_nglp = (uint32_t)nglp;
+        if (q <= 1) { st->q_rec0[q] = nrec; st->q_cell0[q] = cell_off; st->q_unit0[q] = nunit; }
+    }
+    void query_end(int q, uint64_t) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; st->q_nunit[q] = nunit - cur_q_unit; st->q_nglp = (uint32_t)(nglp - cur_q_glp); } }
 };
 
-// Register budget of the strand kernels (the attribute propagates to their callees): H2W_QUAD_WAVES wavefronts per SIMD.
-#define H2W_WAVES __attribute__((amdgpu_waves_per_eu(1, 1)))
-// the PoseidonBN254 chain kernel: two blocks of QUAD_BLOCK threads per CU by LDS (32.9 KB of tables + 10 KB of value slots per wavefront)
+// The PoseidonBN254 emission kernel: two blocks of QUAD_BLOCK threads per CU by LDS (32.9 KB of tables + 10 KB of value slots per wavefront)
 #ifndef H2W_QUAD_EU
 #define H2W_QUAD_EU 2
 #endif
 #define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(H2W_QUAD_EU, H2W_QUAD_EU)))
-template <bool COLS> __global__ __launch_bounds__(64) H2W_WAVES void k_prologue(BatchArgs A) {
-    typedef DevSinkT<COLS> DevSink; typedef ValBackend<DevSink> DevB;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.nproofs) return;
-    DevSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.cc.init(A.cm);
-    DevB be(sink, make_cfg(A, p), true);
-    Verifier<DevB> V(be, A.shape, A.consts);
-    V.prologue(*reinterpret_cast<ChallengeBlock<DevB> *>(&A.cbs[p]));
-    A.status[p] = be.status;
-}
 
-// one wavefront per proof: wave-uniform gadget code, Goldilocks Poseidon split over 12 lanes (coop.h)
-template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_coop(BatchArgs A) {
-    typedef CoopSinkT<COLS> CoopSink; typedef ValBackend<CoopSink> CoopB;
-    if (!(A.dbg_prio & 1)) __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
+template <bool COLS, bool VALPH, int HM> __device__ __forceinline__ void coop_sink_init(CoopSinkT<COLS, VALPH, HM> &sink, const BatchArgs &A, int p, int q) {
+    sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
+    sink.glp = A.glp_list + (uint64_t)p * A.st.total_glp * GLP_LIST_WORDS; sink.small_mds = A.glp_small_mds != 0;
+    sink.bind_lds();
+}
+// one wavefront per proof: wave-uniform gadget code; every rank of a sharded run computes every prologue's VALUES (it needs the
+// challenges); only the proof's owner writes the block (direct cells, records, permutation list)
+template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_values(BatchArgs A) {
+    typedef CoopSinkT<COLS, true> Sink; typedef ValBackend<Sink> CoopB;
+    __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
     stage_glp_consts(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
-    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.nrec = 0; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.cell_off = 0; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.dbg_skip_perm = A.dbg_skip_perm; sink.cc.init(A.cm);
-    sink.bind_lds();
-    sink.emit = own_prologue(A, p);      // every rank of a sharded run needs the challenges; the proof's owner emits the prologue block
+    Sink sink; coop_sink_init(sink, A, p, -1); sink.nrec = 0; sink.cell_off = 0; sink.glp_slot = 0;
+    sink.emit = own_prologue(A, p);
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
     if (threadIdx.x == 0) A.status[p] = be.status ? be.status : sink.load_flag;
 }
 
-// Goldilocks-Poseidon Merkle strands (hash_mode 0): one wavefront per (proof, query, kind); blockIdx.y = kind slot
-template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_coop(BatchArgs A) {
-    typedef CoopSinkT<COLS> CoopSink; typedef ValBackend<CoopSink> CoopB;
-    if (!(A.dbg_prio & 2)) __builtin_amdgcn_s_setprio(3);
+// one wavefront per LISTED Goldilocks-Poseidon permutation of this rank's blocks: the prologues' (every owned proof), then - Goldilocks
+// caps - the Merkle strands' (every owned (proof, query) unit)
+template <bool COLS> __global__ __launch_bounds__(64) void k_glp_emit(BatchArgs A) {
+    typedef CoopSinkT<COLS, false> Sink;
     stage_glp_consts(A.consts, threadIdx.x, 64);
-    const int idx = blockIdx.x, nq = A.shape.num_queries;
-    const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
-    if (!own_unit(A, p, q)) return;
+    unsigned b = blockIdx.x; int p, slot;
+    const unsigned n_pro = A.sh.n_own_proofs * A.st.pro_nglp;
+    if (b < n_pro) { p = (int)(b / A.st.pro_nglp) * A.sh.world + A.sh.rank; slot = (int)(b % A.st.pro_nglp); }
+    else {
+        b -= n_pro; int q;
+        if (A.st.q_nglp == 0 || !own_unit_at(A, b / A.st.q_nglp, p, q)) return;
+        slot = (int)(A.st.pro_nglp + (unsigned)q * A.st.q_nglp + b % A.st.q_nglp);
+    }
+    Sink sink; coop_sink_init(sink, A, p, -1); sink.cell_off = 0; sink.emit = true;
+    const uint64_t *e = A.glp_list + ((uint64_t)p * A.st.total_glp + (uint64_t)slot) * GLP_LIST_WORDS;
+    const uint64_t w = threadIdx.x < GLP_LIST_WORDS ? g_load_u64(e + threadIdx.x) : 0;
+    uint64_t st[SPONGE_WIDTH];
+#pragma unroll
+    for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = readlane64(w, i + 1);
+    sink.nrec = readlane64(w, 0);
+    sink.coop_poseidon_permute(st, A.consts);
+}
+
+// Goldilocks-Poseidon Merkle strands (hash_mode 0), values phase: one wavefront per (owned unit, kind); blockIdx.y = kind slot
+template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(BatchArgs A) {
+    typedef CoopSinkT<COLS, true, 0> Sink; typedef ValBackend<Sink> CoopB;
+    __builtin_amdgcn_s_setprio(3);
+    stage_glp_consts(A.consts, threadIdx.x, 64);
+    int p, q;
+    if (!own_unit_at(A, blockIdx.x, p, q)) return;
+    const int sq = q == 0 ? 0 : 1;
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    CoopSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
+    Sink sink; coop_sink_init(sink, A, p, q); sink.emit = true;
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
-    sink.bind_lds();
+    sink.glp_slot = A.st.pro_nglp + (uint32_t)q * A.st.q_nglp + A.st.mk_glp_rel[kind];
     CoopB be(sink, make_cfg(A, p), true);
     Verifier<CoopB> V(be, A.shape, A.consts);
     const uint64_t x = A.cbs[p].fri_query_indices[q];
     const int lde = V.d.lde_bits; int lo = 0;
     if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
-    uint64_t bits[64]; const int nb = lde - lo;
-    for (int i = 0; i < nb; i++) bits[i] = (x >> (lo + i)) & 1;
     const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
-    V.merkle_strand(q, kind, bits, nb, cap_index);
+    V.merkle_strand(q, kind, PackedBits{x, lo}, lde - lo, cap_index);
     if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
-// PoseidonBN254 Merkle chain strands (hash_mode 1): four lanes per (proof, query, kind); blockIdx.y = kind slot
-template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void k_merkle_bn_quad(BatchArgs A) {
-    typedef QuadSinkT<COLS> QuadSink; typedef ValBackend<QuadSink> QuadB;
-    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);      // (block-wide barrier inside: before any wavefront leaves)
-    const int nq = A.shape.num_queries, total = A.nproofs * nq;
-    if (A.dbg_skip_perm & 16) return;
-    if ((int)((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63)) >> 2) >= total) return;      // a wavefront past the last strand
-    int idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
-    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes)
-    const int p = idx / nq, q = idx % nq, sq = q == 0 ? 0 : 1;
-    if (!own_unit(A, p, q)) return;                     // quad-uniform
-    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
-    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    QuadSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
+// PoseidonBN254 Merkle chains (hash_mode 1).  A quad's strand: (owned unit, kind); its cursor, index bits and unit buffer.
+template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(const BatchArgs &A, Sink &sink, int p, int q, int kind) {
+    const int sq = q == 0 ? 0 : 1;
+    sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
+    sink.ustate = A.unit_state + ((uint64_t)p * A.st.total_unit + strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind]) * 4;
     ValCfg mc = make_cfg(A, p); mc.split_bn = true;
     QuadB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
-    be.unit_idx = strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind];
     Verifier<QuadB> V(be, A.shape, A.consts);
     const uint64_t x = A.cbs[p].fri_query_indices[q];
     const int lde = V.d.lde_bits; int lo = 0;
     if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
-    uint64_t bits[64]; const int nb = lde - lo;
-    for (int i = 0; i < nb; i++) bits[i] = (x >> (lo + i)) & 1;
     const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
-    V.merkle_strand(q, kind, bits, nb, cap_index);
+    V.merkle_strand(q, kind, PackedBits{x, lo}, lde - lo, cap_index);
     if ((threadIdx.x & 3) == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+// values phase: four lanes per (owned unit, kind); blockIdx.y = kind slot
+__global__ __launch_bounds__(QUAD_BLOCK) void k_merkle_bn_values(BatchArgs A) {
+    typedef QuadSinkT<false, QUAD_VALUES> Sink; typedef ValBackend<Sink> QuadB;
+    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);      // (block-wide barrier inside: before any wavefront leaves)
+    const unsigned total = A.sh.n_own_units;
+    if (((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;      // a wavefront past the last strand
+    unsigned idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
+    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes)
+    int p, q; own_unit_at(A, idx, p, q);
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    Sink sink;
+    quad_strand<QuadB>(A, sink, p, q, kind);
+}
+// emission: four lanes per work item = (owned unit, strand kind, permutation unit of that strand)
+template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void k_merkle_bn_emit(BatchArgs A) {
+    typedef QuadSinkT<COLS, QUAD_EMIT> Sink; typedef ValBackend<Sink> QuadB;
+    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);
+    const unsigned per_q = A.st.mk_item0[MK_KINDS];
+    const unsigned long long total = (unsigned long long)A.sh.n_own_units * per_q;
+    if ((((unsigned long long)blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;
+    unsigned long long g = ((unsigned long long)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
+    if (g >= total) g = total - 1;                      // tail quads redo the last item (identical bytes)
+    int p, q; own_unit_at(A, (unsigned)(g / per_q), p, q);
+    const unsigned item = (unsigned)(g % per_q);
+    int kind = 0;
+#pragma unroll 1
+    for (int k = 1; k < MK_KINDS; k++) if (item >= A.st.mk_item0[k]) kind = k;      // (kinds a shape does not have own no items)
+    Sink sink; sink.set_window((int)(item - A.st.mk_item0[kind]), (int)A.st.mk_nunit[kind]);
+    quad_strand<QuadB>(A, sink, p, q, kind);
 }
 
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
@@ -181,9 +227,12 @@ struct h2w_plan {
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
     PlanEqualities eqs;
     fr_t *d_bn_tab = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
+    bool small_mds = false;                           // Goldilocks-Poseidon MDS entries are tiny (coop.h glp_small_mds)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
-    static constexpr int EV_RING = 64, N_EV = 9, N_SIDE = 16;
-    hipEvent_t evr[EV_RING][N_EV];   // per call: 0 start, 1 prologue done, 7 / 2 glue (+ Goldilocks Merkle strands) start / done, 3 expansion done, 4 / 5 chain kernel start / end, 6 end of call, 8 expansion start
+    static constexpr int EV_RING = 64, N_EV = 13, N_SIDE = 16;
+    // per call: 0 start, 9 prologue values done, 11 / 12 permutation-record kernel start / end, 1 prologue block complete, 7 / 2 glue (+ Goldilocks Merkle
+    // strands) start / done, 8 / 3 expansion start / done, 4 / 10 / 5 chain kernels start / values done / end, 6 end of call
+    hipEvent_t evr[EV_RING][N_EV];
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
     int serial_expand = 1;           // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's
     bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
@@ -204,17 +253,10 @@ extern "C" {
 h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t *consts, int device_id) {
     if (!shape || !consts) { set_error("h2w_plan_compile: null argument"); return nullptr; }
     const h2w_shape_t &s = *shape;
-    if (s.lookup_bits < 2 || s.lookup_bits > 28 || s.num_queries < 1 || s.num_queries > MAX_QUERIES || s.cap_height < 0 || (1 << s.cap_height) > MAX_CAP ||
-        s.arity_bits < 1 || (1 << s.arity_bits) > MAX_ARITY || s.n_cols + s.n_perm_z + s.n_quotient > MAX_BATCH_POLYS || s.hash_mode < 0 || s.hash_mode > 1 ||
-        s.degree_bits + s.rate_bits > 63 || s.degree_bits + s.rate_bits < s.cap_height || s.pow_bits < 0 || s.pow_bits > 63 ||
-        s.degree_bits < 0 || s.rate_bits < 0 || s.n_cols < 1 || s.n_perm_z < 0 || s.n_quotient < 1 || s.n_pis < 0 || s.num_challenges < 0 || s.final_poly_bits < 0 ||
-        (s.n_perm_z > 0 && s.perm_batch_size < 1)) {
-        set_error("h2w_plan_compile: unsupported shape"); return nullptr;
-    }
+    if (const char *why = shape_check(s)) { set_error(std::string("h2w_plan_compile: unsupported shape: ") + why); return nullptr; }
     h2w_plan *pl = new h2w_plan(s.lookup_bits);
     pl->shape = s; pl->device = device_id; pl->P = fr_params_init(); pl->h_consts = *consts;
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
-    if (pl->d.final_poly_len > MAX_FINAL_POLY) { set_error("h2w_plan_compile: final polynomial too long"); delete pl; return nullptr; }
     memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1; pl->st.first_zero_unit = -1;
     std::vector<uint64_t> unit_cell; std::vector<LoadItem> items;
     // host inverse table
@@ -248,6 +290,18 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             for (int k2 = 0; k2 < MK_KINDS; k2++) { pl->st.mk_rec_rel[1][k2] = pl->st.mk_rec_rel[0][k2]; pl->st.mk_cell_rel[1][k2] = pl->st.mk_cell_rel[0][k2]; pl->st.mk_nrec[1][k2] = pl->st.mk_nrec[0][k2]; pl->st.mk_ncell[1][k2] = pl->st.mk_ncell[0][k2]; }
         }
         if (pl->st.first_zero_kind == -2) { set_error("h2w_plan_compile: internal: first load_zero outside query 0"); delete pl; return nullptr; }
+        // the two-phase strands' static tables: permutation list slots, emission work items of a query
+        pl->st.total_glp = (uint32_t)sink.nglp;
+        if (s.hash_mode == 1) pl->st.q_nglp = 0;
+        if ((uint64_t)pl->st.pro_nglp + (uint64_t)s.num_queries * pl->st.q_nglp != sink.nglp) { set_error("h2w_plan_compile: internal: permutation list layout"); delete pl; return nullptr; }
+        uint32_t it = 0;
+        for (int k2 = 0; k2 < MK_KINDS; k2++) {
+            pl->st.mk_item0[k2] = it;
+            const bool exists = k2 < 3 ? k2 < pl->d.n_oracles : k2 - 3 < pl->d.n_steps;
+            if (exists) it += pl->st.mk_nunit[k2] ? pl->st.mk_nunit[k2] : 1;
+        }
+        pl->st.mk_item0[MK_KINDS] = it;
+        pl->small_mds = glp_small_mds(*consts);
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -315,21 +369,21 @@ uint64_t h2w_plan_num_chain_cells(const h2w_plan *p) {      // cells of the Merk
     for (int k = 0; k < MK_KINDS; k++) n += p->st.mk_ncell[0][k] + (uint64_t)(p->shape.num_queries - 1) * p->st.mk_ncell[1][k];
     return n;
 }
-static void ws_layout(const h2w_plan *p, uint64_t n, size_t &o_recs, size_t &o_cbs, size_t &o_status, size_t &o_units, size_t &total) {
-    size_t o = 0;
-    o_recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
-    o_cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
-    o_status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
-    o_units = o;
-    o += align_up((size_t)n * sizeof(uint32_t), 256);      // expansion kernel's per-proof tile counters (last region)
-    total = o;
+struct WsLayout { size_t recs, cbs, status, units, glp, ctr, total; };
+static WsLayout ws_layout(const h2w_plan *p, uint64_t n) {
+    WsLayout w; size_t o = 0;
+    w.recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
+    w.cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
+    w.status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
+    w.units = o; o += align_up((size_t)n * p->st.total_unit * 4 * sizeof(fr_t), 256);                  // PoseidonBN254 unit states (values phase -> emission)
+    w.glp = o; o += align_up((size_t)n * p->st.total_glp * GLP_LIST_WORDS * sizeof(uint64_t), 256);     // listed Goldilocks-Poseidon permutations
+    w.ctr = o; o += align_up((size_t)n * sizeof(uint32_t), 256);                                       // expansion kernel's per-proof tile counters
+    w.total = o;
+    return w;
 }
-static size_t ws_ctr_offset(uint64_t n, size_t total) { return total - align_up((size_t)n * sizeof(uint32_t), 256); }
-uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) {
-    if (!p) return 0;
-    size_t a, b, c, d2, t; ws_layout(p, n_proofs, a, b, c, d2, t); return t;
-}
-static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, int shard_rank = 0, int shard_world = 1);
+uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) { return p ? ws_layout(p, n_proofs).total : 0; }
+struct ShardSpec { int rank = 0, world = 1, compact = 0; };
+static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, ShardSpec sh = ShardSpec());
 int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
     ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
     return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_, flat, p ? p->ncells : 0);
@@ -374,108 +428,159 @@ int h2w_fri_witness_batch_columns(h2w_plan *p, const uint64_t *proofs_dev, uint6
     }
     return 0;
 }
-// (proof, query) sharding: this rank generates the prologue block of every proof and the query blocks of the units
-// (proof * num_queries + query) % world == rank, at their global offsets in advice_dev; the other query blocks are left untouched.
+// (proof, query) sharding: this rank LAUNCHES only what it owns - the prologue block of the proofs p % world == rank and the
+// query blocks of the units (proof * num_queries + query) % world == rank (every rank runs every prologue's values: it needs the
+// challenges) - at their global offsets in advice_dev[n_proofs][num_cells]; the other blocks are left untouched.
 int h2w_fri_witness_batch_shard(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) { set_error("h2w_fri_witness_batch_shard: bad rank / world"); return -1; }
     ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
-    return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_, flat, p ? p->ncells : 0, rank, world);
+    ShardSpec sh; sh.rank = rank; sh.world = world;
+    return run_batch(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, stream_, flat, p ? p->ncells : 0, sh);
 }
-static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, int shard_rank, int shard_world) {
+// The same blocks packed into a buffer of h2w_plan_shard_cells cells: the rank's owned blocks back to back in (proof, block) order.
+static uint64_t shard_q_slot(const h2w_plan *p) { return p->st.q_ncell[0] > p->st.q_ncell[1] ? p->st.q_ncell[0] : p->st.q_ncell[1]; }
+static uint64_t own_count(uint64_t total, int rank, int world) { return total > (uint64_t)rank ? (total - (uint64_t)rank + (uint64_t)world - 1) / (uint64_t)world : 0; }
+uint64_t h2w_plan_shard_cells(const h2w_plan *p, uint64_t n_proofs, int rank, int world) {
+    if (!p || world < 1 || rank < 0 || rank >= world) return 0;
+    return own_count(n_proofs, rank, world) * p->st.pro_ncell + own_count(n_proofs * (uint64_t)p->shape.num_queries, rank, world) * shard_q_slot(p);
+}
+int h2w_plan_shard_block(const h2w_plan *p, int rank, int world, uint64_t proof, int query, uint64_t *local_cell, uint64_t *n_cells, uint64_t *global_cell) {
+    if (!p || world < 1 || rank < 0 || rank >= world || query >= p->shape.num_queries) { set_error("h2w_plan_shard_block: bad argument"); return -1; }
+    const uint64_t W = (uint64_t)world, r = (uint64_t)rank, nq = (uint64_t)p->shape.num_queries, u0 = proof * nq;
+    const bool owned = query < 0 ? proof % W == r : (u0 + (uint64_t)query) % W == r;
+    if (!owned) return 1;
+    const uint64_t pro_before = (proof + W - 1 - r) / W, units_before = (u0 + W - 1 - r) / W;
+    uint64_t local = pro_before * p->st.pro_ncell + units_before * shard_q_slot(p), n = p->st.pro_ncell, g = 0;
+    if (query >= 0) {
+        if (proof % W == r) local += p->st.pro_ncell;
+        local += ((u0 + (uint64_t)query + W - 1 - r) / W - units_before) * shard_q_slot(p);
+        n = p->st.q_ncell[query == 0 ? 0 : 1]; g = strand_q_cell(p->st, query);
+    }
+    if (local_cell) *local_cell = local; if (n_cells) *n_cells = n; if (global_cell) *global_cell = g;
+    return 0;
+}
+int h2w_fri_witness_batch_shard_compact(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *shard_advice_dev, void *workspace_dev, void *stream_, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("h2w_fri_witness_batch_shard_compact: bad rank / world"); return -1; }
+    if (p && !(p->shape.lookup_bits == 21 || p->shape.lookup_bits == 13 || p->shape.lookup_bits == 8)) { set_error("h2w_fri_witness_batch_shard_compact: lookup_bits must be 21, 13 or 8 (the packed layout is written by expand_fast)"); return -1; }
+    ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
+    ShardSpec sh; sh.rank = rank; sh.world = world; sh.compact = 1;
+    return run_batch(p, proofs_dev, n_proofs, shard_advice_dev, workspace_dev, stream_, stream_, flat, 0, sh);
+}
+static void fill_expand_shard(const h2w_plan *p, ExpandArgs &E, const ShardSpec &sh) {
+    E.shard_rank = (uint32_t)sh.rank; E.shard_world = (uint32_t)sh.world; E.shard_compact = (uint32_t)sh.compact; E.nq = (uint32_t)p->shape.num_queries;
+    E.pro_nrec = p->st.pro_nrec; E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_first = p->st.q_nrec[0]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
+    if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
+    E.pro_ncell = p->st.pro_ncell; E.q_cell0_first = p->st.q_cell0[0]; E.q_cell0_rest = p->st.q_cell0[1]; E.q_ncell_rest = p->st.q_ncell[1]; E.q_slot = shard_q_slot(p);
+}
+static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, ShardSpec sh) {
     if (!p) { set_error("h2w_fri_witness_batch: null plan"); return -1; }
     if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
-    if (n_proofs * (uint64_t)p->shape.num_queries > 0x7fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
+    if (n_proofs * (uint64_t)p->shape.num_queries * (p->st.mk_item0[MK_KINDS] ? p->st.mk_item0[MK_KINDS] : 1) > 0x3fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
     DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_, estream = (hipStream_t)emit_stream_;
-    size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
+    const WsLayout wl = ws_layout(p, n_proofs);
     char *ws = (char *)workspace_dev;
     BatchArgs A;
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
-    A.recs = (rec_t *)(ws + o_recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm; A.shard_rank = shard_rank; A.shard_world = shard_world;
-    A.cbs = (DevCB *)(ws + o_cbs); A.status = (uint32_t *)(ws + o_status);
-    A.bn_tab = p->d_bn_tab; A.role_base = 0;
-    A.dbg_skip_perm = 0; A.dbg_prio = 0;
-#ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/): never defined in the product build, the results are garbage
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_SKIP_PERM"); dbg = e ? atoi(e) : 0; } A.dbg_skip_perm = dbg; }
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("H2W_DBG_PRIO"); dbg = e ? atoi(e) : 0; } A.dbg_prio = dbg; }      // 1: prologue, 2: Goldilocks Merkle strands without s_setprio; 4: glue strands with it
-#endif
+    A.recs = (rec_t *)(ws + wl.recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
+    A.cbs = (DevCB *)(ws + wl.cbs); A.status = (uint32_t *)(ws + wl.status);
+    A.unit_state = (fr_t *)(ws + wl.units); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
+    A.bn_tab = p->d_bn_tab;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
-    p->ev = p->evr[p->n_batches % h2w_plan::EV_RING];
-    hipStream_t cstream = stream;      // chain kernel's stream
+    A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p);
+    A.sh.n_own_units = (uint32_t)own_count(n_proofs * (uint64_t)p->shape.num_queries, sh.rank, sh.world);
+    A.sh.n_own_proofs = (uint32_t)own_count(n_proofs, sh.rank, sh.world);
+    hipStream_t cstream = stream;      // chain kernels' stream
     if (p->fork_chains && p->shape.hash_mode == 1) {
         int k = 0; while (k < p->n_side && p->side_of[k] != stream) k++;
         if (k == p->n_side && p->n_side < h2w_plan::N_SIDE) {
-            int lo_pri = 0, hi_pri = 0; (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);      // the chain kernel is the longest dependent piece of a launch: let its blocks be placed first
+            int lo_pri = 0, hi_pri = 0; (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);      // the chain is the longest dependent piece of a launch: let its blocks be placed first
             H2W_HIP(hipStreamCreateWithPriority(&p->side[k], hipStreamNonBlocking, hi_pri)); p->side_of[k] = stream; p->n_side++;
         }
         if (k < p->n_side) cstream = p->side[k];      // (more caller streams than side streams: the extra ones do not fork)
     }
-    hipEvent_t *prev_ev = p->n_batches ? p->evr[(p->n_batches - 1) % h2w_plan::EV_RING] : nullptr;
-    p->n_batches++;
-    hipEvent_t *ev = p->ev;
-    int dbg_skip = 0;
-#ifdef H2W_DEBUG_HOOKS   // H2W_DBG_SKIP_KERNELS bitmask: 1 prologue, 2 strands, 4 expansion (timing experiments only: the results are garbage)
-    { static int env_skip = -1; if (env_skip < 0) { const char *e = getenv("H2W_DBG_SKIP_KERNELS"); env_skip = e ? atoi(e) : 0; } dbg_skip = env_skip; }
-#endif
-    H2W_HIP(hipEventRecord(ev[0], stream));
-    // 1. prologue strands: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks
-    if (!(dbg_skip & 1)) { if (cm.starts) hipLaunchKernelGGL(k_prologue_coop<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_coop<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); }
-    H2W_HIP(hipEventRecord(ev[1], stream));
-    const unsigned nlanes = (unsigned)(n_proofs * (uint64_t)p->shape.num_queries);
+    hipEvent_t *prev_ev = (p->n_batches && p->ev_recorded) ? p->evr[(p->n_batches - 1) % h2w_plan::EV_RING] : nullptr;
+    hipEvent_t *ev = p->evr[p->n_batches % h2w_plan::EV_RING];
+    const unsigned nunits = A.sh.n_own_units;
     const unsigned nkinds = (unsigned)(p->d.n_oracles + p->d.n_steps);
-    // 2. PoseidonBN254 Merkle chain strands (hash_mode 1): four lanes per (proof, query, tree); they emit their permutations' cells
-    //    themselves and write no block records, so nothing but the prologue orders them against the glue strands and the expansion
-    //    kernel of the same batch: they run on a side stream of the plan and rejoin at the end of the call.
-    if (p->shape.hash_mode == 1) {
-        if (cstream != stream) H2W_HIP(hipStreamWaitEvent(cstream, ev[1], 0));
-        H2W_HIP(hipEventRecord(ev[4], cstream));
-        const dim3 qgrid((nlanes * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, nkinds);
-        if (!(dbg_skip & 2)) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_quad<true>, qgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_quad<false>, qgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
-        H2W_HIP(hipEventRecord(ev[5], cstream));
-    }
-    // 3. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per (proof, query);
-    //    Goldilocks-Poseidon Merkle strands (hash_mode 0): one cooperating wavefront per (proof, query, tree) - these do write records
-    H2W_HIP(hipEventRecord(ev[7], stream));
-    if (!(dbg_skip & 2)) {
-        launch_glue_strands(A, nlanes, stream);
-        if (p->shape.hash_mode == 0) {
-            if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_coop<true>, dim3(nlanes, nkinds), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_merkle_gl_coop<false>, dim3(nlanes, nkinds), dim3(64), 0, stream, A);
+    bool forked = false;
+    auto body = [&]() -> int {
+        H2W_HIP(hipEventRecord(ev[0], stream));
+        // 1. prologue strands, values: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks
+        if (cm.starts) hipLaunchKernelGGL(k_prologue_values<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_values<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
+        H2W_HIP(hipEventRecord(ev[9], stream));
+        // 2. PoseidonBN254 Merkle chains (hash_mode 1): values, then one quad per permutation unit.  They write their cells themselves and no
+        //    block records, so nothing but the challenge blocks orders them against the other kernels of the batch: they run on a side
+        //    stream of the plan and rejoin at the end of the call.
+        if (p->shape.hash_mode == 1) {
+            if (cstream != stream) { H2W_HIP(hipStreamWaitEvent(cstream, ev[9], 0)); forked = true; }
+            H2W_HIP(hipEventRecord(ev[4], cstream));
+            if (nunits) hipLaunchKernelGGL(k_merkle_bn_values, dim3((nunits * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, nkinds), dim3(QUAD_BLOCK), 0, cstream, A);
+            H2W_HIP(hipEventRecord(ev[10], cstream));
+            const unsigned long long items = (unsigned long long)nunits * p->st.mk_item0[MK_KINDS];
+            if (items) {
+                const dim3 egrid((unsigned)((items * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK));
+                if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_emit<true>, egrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_emit<false>, egrid, dim3(QUAD_BLOCK), 0, cstream, A);
+            }
+            H2W_HIP(hipEventRecord(ev[5], cstream));
         }
+        // 3. the records of the listed Goldilocks-Poseidon permutations: with PoseidonBN254 caps the prologues' (now); with Goldilocks caps
+        //    together with the Merkle strands' (below)
+        const unsigned n_pro_perms = A.sh.n_own_proofs * p->st.pro_nglp, n_mk_perms = nunits * p->st.q_nglp;
+        auto glp_emit = [&](unsigned n) -> int {
+            H2W_HIP(hipEventRecord(ev[11], stream));
+            if (n) { if (cm.starts) hipLaunchKernelGGL(k_glp_emit<true>, dim3(n), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_glp_emit<false>, dim3(n), dim3(64), 0, stream, A); }
+            H2W_HIP(hipEventRecord(ev[12], stream));
+            return 0;
+        };
+        if (p->shape.hash_mode == 1) { if (glp_emit(n_pro_perms) != 0) return -1; }
+        H2W_HIP(hipEventRecord(ev[1], stream));
+        // 4. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per owned (proof, query);
+        //    Goldilocks-Poseidon Merkle strands (hash_mode 0), values: one cooperating wavefront per (proof, query, tree)
+        H2W_HIP(hipEventRecord(ev[7], stream));
+        if (nunits) {
+            launch_glue_strands(A, stream);
+            if (p->shape.hash_mode == 0) {
+                if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_values<true>, dim3(nunits, nkinds), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_merkle_gl_values<false>, dim3(nunits, nkinds), dim3(64), 0, stream, A);
+            }
+        }
+        if (p->shape.hash_mode == 0) { if (glp_emit(n_pro_perms + n_mk_perms) != 0) return -1; }
+        H2W_HIP(hipEventRecord(ev[2], stream));
+        if (p->shape.hash_mode == 0) { H2W_HIP(hipEventRecord(ev[4], stream)); H2W_HIP(hipEventRecord(ev[10], stream)); H2W_HIP(hipEventRecord(ev[5], stream)); }
+        // 5. expansion of the block records (HBM-write-bound)
+        ExpandArgs E;
+        E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
+        fill_expand_shard(p, E, sh);
+        p->dt.fill(E);
+        E.tile_ctr = (uint32_t *)(ws + wl.ctr);
+        E.roam_per_cu = p->shape.hash_mode == 0 ? 2 : 1;      // (profiles/r02_expand_grid.txt)
+        int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
+        if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, ev[2], 0));    // value strands done -> expansion on the emit stream
+        H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
+        // One expansion kernel at a time over all the streams a plan is driven on: its blocks are persistent and hold their CUs until the
+        // launch is written, so two of them side by side keep the latency-bound strands of the other launches in flight off the chip
+        // (measured: +8..12 % for the whole job with PoseidonBN254 caps, profiles/r02_sweep5.txt; +5 % with Goldilocks caps since that kernel
+        // runs on a grid of resident blocks there and reaches its rate alone, profiles/r02_expand_grid.txt).
+        if (p->serial_expand != 0 && prev_ev) H2W_HIP(hipStreamWaitEvent(estream, prev_ev[3], 0));
+        H2W_HIP(hipEventRecord(ev[8], estream));
+        if (launch_expand(E, n_proofs, gx, estream) != 0) return -1;
+        H2W_HIP(hipEventRecord(ev[3], estream));
+        if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, ev[3], 0));    // the caller's stream completes when the advice is complete
+        if (forked) { H2W_HIP(hipStreamWaitEvent(stream, ev[5], 0)); forked = false; }
+        H2W_HIP(hipEventRecord(ev[6], stream));
+        H2W_HIP(hipGetLastError());
+        return 0;
+    };
+    if (body() != 0) {
+        // a failed enqueue after the fork: the chain kernels may still be writing advice / workspace on the side stream and nothing orders the
+        // caller's stream behind them any more - wait for them here, so that the caller may release the buffers when it sees the error
+        if (forked) (void)hipStreamSynchronize(cstream);
+        return -1;
     }
-    H2W_HIP(hipEventRecord(ev[2], stream));
-    if (p->shape.hash_mode == 0) { H2W_HIP(hipEventRecord(ev[4], stream)); H2W_HIP(hipEventRecord(ev[5], stream)); }
-    // 4. expansion of the block records (HBM-write-bound)
-    ExpandArgs E;
-    E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
-    E.shard_rank = (uint32_t)shard_rank; E.shard_world = (uint32_t)shard_world; E.nq = (uint32_t)p->shape.num_queries;
-    E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
-    if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
-    p->dt.fill(E);
-    E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
-    E.roam_per_cu = p->shape.hash_mode == 0 ? 2 : 1;      // (profiles/r02_expand_grid.txt)
-    int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
-#ifdef H2W_DEBUG_HOOKS
-    { static int dgx = -1; if (dgx < 0) { const char *e = getenv("H2W_DBG_EXPAND_GX"); dgx = e ? atoi(e) : 0; } if (dgx > 0) gx = dgx; }
-#endif
-    if (estream != stream) H2W_HIP(hipStreamWaitEvent(estream, ev[2], 0));    // value strands done -> expansion on the emit stream
-    H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), estream));
-    // One expansion kernel at a time over all the streams a plan is driven on: its blocks are persistent and hold their CUs until the
-    // launch is written, so two of them side by side keep the latency-bound strands of the other launches in flight off the chip
-    // (measured: +8..12 % for the whole job with PoseidonBN254 caps, profiles/r02_sweep5.txt; +5 % with Goldilocks caps since that kernel
-    // runs on a grid of resident blocks there and reaches its rate alone, profiles/r02_expand_grid.txt).
-    const bool serial = p->serial_expand != 0;
-    if (serial && prev_ev && p->ev_recorded) H2W_HIP(hipStreamWaitEvent(estream, prev_ev[3], 0));
-    H2W_HIP(hipEventRecord(ev[8], estream));
-    if (!(dbg_skip & 4)) launch_expand(E, n_proofs, gx, estream);
-    H2W_HIP(hipEventRecord(ev[3], estream));
-    if (estream != stream) H2W_HIP(hipStreamWaitEvent(stream, ev[3], 0));    // the caller's stream completes when the advice is complete
-    if (p->shape.hash_mode == 1 && cstream != stream) H2W_HIP(hipStreamWaitEvent(stream, ev[5], 0));
-    H2W_HIP(hipEventRecord(ev[6], stream));
-    p->ev_recorded = true;
-    H2W_HIP(hipGetLastError());
+    p->ev = ev; p->n_batches++; p->ev_recorded = true;
     return 0;
 }
 // Re-expands the block records a previous h2w_fri_witness_batch* call left in `workspace_dev` (same n_proofs) into advice_dev: the
@@ -486,20 +591,18 @@ int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, voi
     if (n_proofs == 0) return 0;
     DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
-    size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
+    const WsLayout wl = ws_layout(p, n_proofs);
     char *ws = (char *)workspace_dev;
     ExpandArgs E;
-    E.meta = p->d_meta; E.recs = (rec_t *)(ws + o_recs); E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = (fr_t *)advice_dev; E.cell_stride = p->ncells; E.pool = nullptr;
+    E.meta = p->d_meta; E.recs = (rec_t *)(ws + wl.recs); E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = (fr_t *)advice_dev; E.cell_stride = p->ncells; E.pool = nullptr;
     E.cm = ColMap{nullptr, 0, 0};
-    E.shard_rank = 0; E.shard_world = 1; E.nq = (uint32_t)p->shape.num_queries;
-    E.q_rec0_first = p->st.q_rec0[0]; E.q_rec0_rest = p->st.q_rec0[1]; E.q_nrec_rest = p->st.q_nrec[1] ? p->st.q_nrec[1] : 1;
-    if (p->shape.num_queries == 1) E.q_rec0_rest = ~0ull;
+    fill_expand_shard(p, E, ShardSpec());
     p->dt.fill(E);
-    E.tile_ctr = (uint32_t *)(ws + ws_ctr_offset(n_proofs, total));
+    E.tile_ctr = (uint32_t *)(ws + wl.ctr);
     E.roam_per_cu = p->shape.hash_mode == 0 ? 2 : 1;      // (profiles/r02_expand_grid.txt)
     H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * sizeof(uint32_t), stream));
     int gx = (int)(2048 / (n_proofs < 2048 ? n_proofs : 2048)); if (gx < 8) gx = 8;
-    launch_expand(E, n_proofs, gx, stream);
+    if (launch_expand(E, n_proofs, gx, stream) != 0) return -1;
     H2W_HIP(hipGetLastError());
     return 0;
 }
@@ -723,10 +826,10 @@ int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proo
 }
 int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {
     if (!p || !workspace_dev || !host_status) { set_error("h2w_plan_status: null argument"); return -1; }
-    size_t o_recs, o_cbs, o_status, o_units, total; ws_layout(p, n_proofs, o_recs, o_cbs, o_status, o_units, total);
+    const WsLayout wl = ws_layout(p, n_proofs);
     DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
-    H2W_HIP(hipMemcpyAsync(host_status, (const char *)workspace_dev + o_status, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    H2W_HIP(hipMemcpyAsync(host_status, (const char *)workspace_dev + wl.status, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     H2W_HIP(hipStreamSynchronize(stream));
     return 0;
 }
@@ -760,11 +863,26 @@ int h2w_plan_timing(h2w_plan *p, uint64_t back, float ms[5]) {   // `back` batch
     hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
     DeviceGuard dg(p->device);
     H2W_HIP(hipEventSynchronize(ev[6]));
-    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));   // prologue strands
-    H2W_HIP(hipEventElapsedTime(&ms[1], ev[7], ev[2]));   // query glue strands (+ Goldilocks-Poseidon Merkle strands)
-    H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[5]));   // PoseidonBN254 Merkle chain kernel (on its side stream; 0 for Goldilocks-Poseidon Merkle)
+    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));   // prologue strands: values (+ with PoseidonBN254 caps: their permutations' records)
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[7], ev[2]));   // query glue strands (+ Goldilocks caps: Merkle strands, values, and every listed permutation's records)
+    H2W_HIP(hipEventElapsedTime(&ms[2], ev[4], ev[5]));   // PoseidonBN254 Merkle chains: values + emission (on their side stream; 0 for Goldilocks-Poseidon Merkle)
     H2W_HIP(hipEventElapsedTime(&ms[3], ev[8], ev[3]));   // expansion kernel
     H2W_HIP(hipEventElapsedTime(&ms[4], ev[0], ev[6]));   // whole call
+    return 0;
+}
+int h2w_plan_timing_ex(h2w_plan *p, uint64_t back, float ms[8]) {
+    if (!p || !p->ev_recorded || back >= p->n_batches || back >= (uint64_t)h2w_plan::EV_RING) { set_error("h2w_plan_timing_ex: no such batch"); return -1; }
+    hipEvent_t *ev = p->evr[(p->n_batches - 1 - back) % h2w_plan::EV_RING];
+    DeviceGuard dg(p->device);
+    H2W_HIP(hipEventSynchronize(ev[6]));
+    H2W_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[9]));    // k_prologue_values
+    H2W_HIP(hipEventElapsedTime(&ms[1], ev[11], ev[12]));  // k_glp_emit
+    H2W_HIP(hipEventElapsedTime(&ms[2], ev[7], p->shape.hash_mode == 0 ? ev[11] : ev[2]));   // k_strands (+ k_merkle_gl_values)
+    H2W_HIP(hipEventElapsedTime(&ms[3], ev[4], ev[10]));   // k_merkle_bn_values
+    H2W_HIP(hipEventElapsedTime(&ms[4], ev[10], ev[5]));   // k_merkle_bn_emit
+    H2W_HIP(hipEventElapsedTime(&ms[5], ev[8], ev[3]));    // expansion kernel
+    H2W_HIP(hipEventElapsedTime(&ms[6], ev[0], ev[6]));    // whole call
+    ms[7] = 0;
     return 0;
 }
 int h2w_plan_last_timing(h2w_plan *p, float ms[5]) { return h2w_plan_timing(p, 0, ms); }

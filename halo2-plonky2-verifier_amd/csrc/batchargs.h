@@ -7,6 +7,16 @@ namespace h2w {
 typedef ValBackend<DevSink> DevB;
 typedef ChallengeBlock<DevB> DevCB;   // (the wire types of every backend coincide: one ChallengeBlock layout)
 
+// (proof, query) sharding of a launch (fri/mod.rs:488-501 is the loop being dealt out): unit u = proof * num_queries + query
+// belongs to rank u % world, the prologue block of proof p to rank p % world.  A rank LAUNCHES only what it owns: its i-th unit is
+// u = i * world + rank, its j-th proof p = j * world + rank (world 1: everything).
+// compact != 0: the rank's advice buffer holds only its own blocks, back to back in (proof, block) order - its j-th owned prologue block
+// and i-th owned query block start at local cell j * pro_ncell + i * q_slot (q_slot = the larger of the two query block sizes);
+// compact == 0: every block at its global offset in advice[n_proofs][num_cells].
+struct ShardMap {
+    int rank, world, compact; uint32_t n_own_units, n_own_proofs; uint64_t q_slot;
+};
+
 struct BatchArgs {
     h2w_shape_t shape; const h2w_poseidon_consts_t *consts;
     const uint64_t *proofs; uint64_t proof_words;
@@ -15,14 +25,39 @@ struct BatchArgs {
     DevCB *cbs; uint32_t *status;
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg;
     StrandTable st; FrParams P;
-    int nproofs, role_base, dbg_skip_perm, dbg_prio;
+    int nproofs;
     const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
+    fr_t *unit_state;               // [nproofs][st.total_unit][4]: output state of every PoseidonBN254 permutation unit (values phase -> emission)
+    uint64_t *glp_list;             // [nproofs][st.total_glp][GLP_LIST_WORDS]: the listed Goldilocks-Poseidon permutations (values phase -> record emission)
+    int glp_small_mds;
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
     ColMap cm;      // column-major emission (starts == nullptr: flat advice)
-    int shard_rank, shard_world;      // (proof, query) units are dealt round-robin to shard_world ranks (1: everything)
+    ShardMap sh;
 };
-__device__ __forceinline__ bool own_prologue(const BatchArgs &A, int p) { return A.shard_world <= 1 || p % A.shard_world == A.shard_rank; }      // rank proof_id mod world
-__device__ __forceinline__ bool own_unit(const BatchArgs &A, int p, int q) { return A.shard_world <= 1 || (int)(((long long)p * A.shape.num_queries + q) % A.shard_world) == A.shard_rank; }
+__device__ __forceinline__ bool own_prologue(const BatchArgs &A, int p) { return A.sh.world <= 1 || p % A.sh.world == A.sh.rank; }
+// the i-th (proof, query) unit of this rank; false past the last one
+__device__ __forceinline__ bool own_unit_at(const BatchArgs &A, unsigned i, int &p, int &q) {
+    if (i >= A.sh.n_own_units) return false;
+    const unsigned long long u = (unsigned long long)i * (unsigned)A.sh.world + (unsigned)A.sh.rank;
+    p = (int)(u / (unsigned)A.shape.num_queries); q = (int)(u % (unsigned)A.shape.num_queries);
+    return true;
+}
+// Where the cells of proof p's block (q < 0: prologue, else query q) go: the pointer that the block's GLOBAL in-proof cell offsets are
+// added to.  Flat layout: out + p * cell_stride.  Compact layout: shifted so that the block lands in the rank's packed buffer.
+__device__ __forceinline__ fr_t *block_out(const BatchArgs &A, int p, int q) {
+    if (!A.sh.compact) return A.out + (uint64_t)p * A.cell_stride;
+    const uint64_t W = (uint64_t)A.sh.world, r = (uint64_t)A.sh.rank;
+    const uint64_t u0 = (uint64_t)p * (uint64_t)A.shape.num_queries;
+    const uint64_t pro_before = ((uint64_t)p + W - 1 - r) / W, units_before = (u0 + W - 1 - r) / W;      // owned prologues / units of the proofs before p
+    uint64_t local = pro_before * A.st.pro_ncell + units_before * A.sh.q_slot, global = 0;
+    if (q >= 0) {
+        if ((uint64_t)p % W == r) local += A.st.pro_ncell;
+        const uint64_t u = u0 + (uint64_t)q;
+        local += ((u + W - 1 - r) / W - units_before) * A.sh.q_slot;      // owned units of this proof before query q
+        global = strand_q_cell(A.st, q);
+    }
+    return A.out + local - global;
+}
 
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
@@ -32,6 +67,6 @@ __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     return c;
 }
 
-void launch_glue_strands(const BatchArgs &A, unsigned nlanes, hipStream_t stream);      // glue.hip
+void launch_glue_strands(const BatchArgs &A, hipStream_t stream);      // glue.hip
 
 }  // namespace h2w

@@ -13,7 +13,7 @@
 namespace h2w {
 
 struct CountSink {       // host: lays out the instance (record metas, cell count)
-    static constexpr bool kCoop = false, kSplitOnly = false;
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = -1;
     const TemplateTable *tt; std::vector<uint64_t> meta; uint64_t cell_off = 0;
     void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta.push_back(meta_pack((uint32_t)t, cell_off)); cell_off += (uint64_t)tt->ncells(t); }
     void cell(const fr_t &) { cell_off++; }
@@ -136,11 +136,11 @@ int h2w_chipbatch_run(h2w_chipbatch *h, const uint64_t *operands_dev, uint64_t n
             hipLaunchKernelGGL(k_chip_batch, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, stream, A);
             ExpandArgs E;
             E.meta = h->d_meta; E.recs = A.recs; E.nrec = h->nrec; E.rec_stride = h->nrec; E.out = A.out; E.cell_stride = h->ncells; E.pool = nullptr;
-            E.cm = ColMap{nullptr, 0, 0}; E.shard_rank = 0; E.shard_world = 1; E.nq = 1; E.q_rec0_first = E.q_rec0_rest = ~0ull; E.q_nrec_rest = 1;
+            E.cm = ColMap{nullptr, 0, 0}; expand_unsharded(E);
             h->dt.fill(E);
             E.tile_ctr = (uint32_t *)(ws + b_recs);
             H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, m * sizeof(uint32_t), stream));
-            launch_expand(E, m, 1, stream);
+            if (launch_expand(E, m, 1, stream) != 0) return -1;
             H2W_HIP(hipGetLastError());
         }
         return 0;

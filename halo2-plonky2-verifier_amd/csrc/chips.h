@@ -14,7 +14,7 @@ namespace h2w {
 
 constexpr int SPONGE_WIDTH = 12, SPONGE_RATE = 8, HALF_N_FULL_ROUNDS = 4, N_PARTIAL_ROUNDS = 22, NUM_HASH_OUT_ELTS = 4;
 constexpr int BN_WIDTH = 4, BN_RATE = 3, BN_FULL_ROUNDS = 8, BN_PARTIAL_ROUNDS = 56;
-constexpr int MAX_STEPS = 8, MAX_ARITY = 16, MAX_CAP = 16, MAX_BATCH_POLYS = 16, MAX_FINAL_POLY = 128;
+constexpr int MAX_STEPS = 8, MAX_ARITY = 16, MAX_CAP = 64, MAX_BATCH_POLYS = 16, MAX_FINAL_POLY = 128;      // MAX_CAP: cap_height <= 6 (sizes only the host-side / Goldilocks-caps indicator arrays)
 enum { PRE_NONE = 0, PRE_A = 1, PRE_B = 2 };
 
 // shape-derived quantities (plonky2 FriParams)
@@ -237,10 +237,11 @@ template <class B> struct PoseidonPermutationChip {
     }
     HF void load_zero(Gl *st) { gl.load_zero_array(SPONGE_WIDTH, st); }               // :264-268
     HNI void permute(Gl *st) {                                                        // :270-284
+        be.glp_note();
         if constexpr (B::kCoopPoseidon) be.coop_poseidon_permute(st, k);              // one wavefront cooperates on the 12-wide state (coop.h)
         else { int rc = 0; full_rounds(st, rc); partial_rounds(st, rc); full_rounds(st, rc); }
     }
-    HF void absorb_goldilocks(Gl *st, const Gl *in, int n) {                          // :286-301 (overwrite mode)
+    template <class In> HF void absorb_goldilocks(Gl *st, const In &in, int n) {      // :286-301 (overwrite mode); `in`: anything indexable
         for (int off = 0; off < n; off += SPONGE_RATE) {
             int len = n - off < SPONGE_RATE ? n - off : SPONGE_RATE;
             for (int i = 0; i < len; i++) st[i] = in[off + i];
@@ -289,15 +290,20 @@ template <class B> struct PoseidonBN254PermutationChip {
         if (is_first) { ark(st, (BN_FULL_ROUNDS / 2) * BN_WIDTH); mix(st, p); } else mix(st, m);
     }
     HF void permute(Fr *st) {                                                                         // :190-203
-        if (be.bn_perm_unit(st, k)) return;     // device chain strands: only the output state is needed here; the 4,032 cells are emitted by the unit kernel
+        if constexpr (B::kBnUnits) { be.bn_perm_unit(st, k); return; }      // device chain strands: the quad's sink computes / emits the permutation unit (coop.h)
+        else if (be.bn_perm_unit(st, k)) return;
         be.bn_perm_begin();
         ark(st, 0); full_rounds(st, true); partial_rounds(st); full_rounds(st, false);
         be.bn_perm_end();
     }
-    HF void absorb_goldilocks(Fr *st, const Gl *in, int n) {                                          // :205-228
+    template <class In> HF void absorb_goldilocks(Fr *st, const In &in, int n) {                      // :205-228
         for (int off = 0; off < n; off += BN_RATE * 3) {
             int len = n - off < BN_RATE * 3 ? n - off : BN_RATE * 3;
-            for (int j = 0, o = 0; o < len; j++, o += 3) { int l3 = len - o < 3 ? len - o : 3; st[j + 1] = be.limbs_to_num(in + off + o, l3); }
+            for (int j = 0, o = 0; o < len; j++, o += 3) {
+                int l3 = len - o < 3 ? len - o : 3; Gl t[3];
+                for (int u = 0; u < 3; u++) t[u] = in[off + o + (u < l3 ? u : 0)];
+                st[j + 1] = be.limbs_to_num(t, l3);
+            }
             permute(st);
         }
     }
@@ -309,29 +315,32 @@ template <class B> struct HasherChip {
     typedef typename B::Gl Gl; typedef typename B::Bool Bool; typedef typename B::Fr Fr; typedef HashW<B> H;
     B &be; int mode; GoldilocksChip<B> gl; PoseidonPermutationChip<B> pg; PoseidonBN254PermutationChip<B> pb;
     HF HasherChip(B &b, int hash_mode, const h2w_poseidon_consts_t *k) : be(b), mode(hash_mode), gl(b), pg(b, k), pb(b, k) {}
-    HF int max_goldilocks() const { return mode == 0 ? NUM_HASH_OUT_ELTS : 3; }
+    // the hash mode: a run-time field of the shape, or fixed by the backend (B::kHashMode >= 0: a kernel that only ever runs one kind of
+    // Merkle strand does not carry the other hash's code and stack frames)
+    HF int md() const { if constexpr (B::kHashMode >= 0) return B::kHashMode; else return mode; }
+    HF int max_goldilocks() const { return md() == 0 ? NUM_HASH_OUT_ELTS : 3; }
     HF H load_witness(const uint64_t *w) {    // poseidon/hash.rs:86-96 (as constants!) ; poseidon_bn254/hash.rs:89-98
         H h;
-        if (mode == 0) be.gl_const4(w, h.e);
+        if (md() == 0) be.gl_const4(w, h.e);
         else { fr_t v; v.l[0] = w[0]; v.l[1] = w[1]; v.l[2] = w[2]; v.l[3] = w[3]; h.f = be.fr_witness(v); }
         return h;
     }
-    HF H load_goldilocks_slice(const Gl *in, int n) {          // poseidon/hash.rs:98-112 ; poseidon_bn254/hash.rs:100-114
+    template <class In> HF H load_goldilocks_slice(const In &in, int n) {   // poseidon/hash.rs:98-112 ; poseidon_bn254/hash.rs:100-114
         H h;
-        if (mode == 0) { gl.load_zero_array(NUM_HASH_OUT_ELTS, h.e); for (int i = 0; i < n; i++) h.e[i] = in[i]; }
-        else h.f = be.limbs_to_num(in, n);
+        if (md() == 0) { gl.load_zero_array(NUM_HASH_OUT_ELTS, h.e); for (int i = 0; i < n; i++) h.e[i] = in[i]; }
+        else { Gl t[3]; for (int u = 0; u < 3; u++) t[u] = in[u < n ? u : 0]; h.f = be.limbs_to_num(t, n); }
         return h;
     }
-    HNI H hash_no_pad(const Gl *in, int n) {                    // poseidon/hash.rs:161-184 ; poseidon_bn254/hash.rs:156-179
+    template <class In> HF H hash_no_pad(const In &in, int n) {  // poseidon/hash.rs:161-184 ; poseidon_bn254/hash.rs:156-179
         H h;
-        if (mode == 0) { Gl st[SPONGE_WIDTH]; gl.load_zero_array(SPONGE_WIDTH, st); pg.absorb_goldilocks(st, in, n); for (int i = 0; i < 4; i++) h.e[i] = st[i]; }
+        if (md() == 0) { Gl st[SPONGE_WIDTH]; gl.load_zero_array(SPONGE_WIDTH, st); pg.absorb_goldilocks(st, in, n); for (int i = 0; i < 4; i++) h.e[i] = st[i]; }
         else { Fr st[BN_WIDTH]; be.fr_zero_consts4(st); pb.absorb_goldilocks(st, in, n); h.f = st[0]; }
         return h;
     }
-    HF H hash_or_noop(const Gl *in, int n) { return n <= max_goldilocks() ? load_goldilocks_slice(in, n) : hash_no_pad(in, n); } // hash/mod.rs:109-119
+    template <class In> HF H hash_or_noop(const In &in, int n) { return n <= max_goldilocks() ? load_goldilocks_slice(in, n) : hash_no_pad(in, n); } // hash/mod.rs:109-119
     HNI H two_to_one(const H &l, const H &r) {                  // poseidon/hash.rs:187-214 ; poseidon_bn254/hash.rs:182-209
         H h;
-        if (mode == 0) {
+        if (md() == 0) {
             Gl st[SPONGE_WIDTH]; gl.load_zero_array(SPONGE_WIDTH, st);
             for (int i = 0; i < 4; i++) { st[i] = l.e[i]; st[4 + i] = r.e[i]; }
             pg.permute(st); for (int i = 0; i < 4; i++) h.e[i] = st[i];
@@ -340,22 +349,22 @@ template <class B> struct HasherChip {
     }
     HNI H select(const H &a, const H &b, Bool sel) {            // poseidon/hash.rs:114-126 ; poseidon_bn254/hash.rs:116-127
         H h;
-        if (mode == 0) gl.select_array(a.e, b.e, 4, sel, h.e); else h.f = be.fr_select(a.f, b.f, sel);
+        if (md() == 0) gl.select_array(a.e, b.e, 4, sel, h.e); else h.f = be.fr_select(a.f, b.f, sel);
         return h;
     }
     template <class CapFn> HF H select_from_idx(int n, CapFn cap, Gl idx) {   // poseidon/hash.rs:128-146 ; poseidon_bn254/hash.rs:129-143
         H h;
-        if (mode == 0) {
+        if (md() == 0) {
             Bool ind[MAX_CAP]; be.idx_to_indicator(idx, n, ind);
             for (int j = 0; j < 4; j++) { Gl col[MAX_CAP]; for (int i = 0; i < n; i++) col[i] = cap(i).e[j]; h.e[j] = be.select_by_indicator(col, 1, ind, n); }
-        } else { Fr col[MAX_CAP]; for (int i = 0; i < n; i++) col[i] = cap(i).f; h.f = be.fr_select_from_idx(col, n, idx); }
+        } else h.f = be.fr_select_from_idx_fn(n, [&](int i) { return cap(i).f; }, idx);      // (no per-lane column array on the device)
         return h;
     }
     HF void assert_equal(const H &a, const H &b) {      // poseidon/hash.rs:148-159 ; poseidon_bn254/hash.rs:145-154
-        if (mode == 0) { for (int i = 0; i < 4; i++) be.assert_equal(a.e[i], b.e[i]); } else be.assert_equal_fr(a.f, b.f);
+        if (md() == 0) { for (int i = 0; i < 4; i++) be.assert_equal(a.e[i], b.e[i]); } else be.assert_equal_fr(a.f, b.f);
     }
     HF int to_goldilocks_vec(const H &h, Gl *out) {            // poseidon/hash.rs:22-30 ; poseidon_bn254/hash.rs:29-44
-        if (mode == 0) { for (int i = 0; i < 4; i++) out[i] = h.e[i]; return 4; }
+        if (md() == 0) { for (int i = 0; i < 4; i++) out[i] = h.e[i]; return 4; }
         be.decompose_le_56_5(h.f, out); return 5;
     }
 };
@@ -365,8 +374,8 @@ template <class B> struct MerkleTreeChip {
     typedef typename B::Gl Gl; typedef typename B::Bool Bool; typedef HashW<B> H;
     B &be; HasherChip<B> hs;
     HF MerkleTreeChip(B &b, int mode, const h2w_poseidon_consts_t *k) : be(b), hs(b, mode, k) {}
-    template <class SibFn, class CapFn>
-    HF void verify_proof_to_cap_with_cap_index(const Gl *leaf, int n_leaf, const Bool *bits, int n_bits, Gl cap_index,
+    template <class LeafT, class BitsT, class SibFn, class CapFn>      // leaf / bits: anything indexable (arrays, proof-word views, packed index bits)
+    HF void verify_proof_to_cap_with_cap_index(const LeafT &leaf, int n_leaf, const BitsT &bits, int n_bits, Gl cap_index,
                                                int n_cap, CapFn cap, int n_sib, SibFn sibling) {
         H node = hs.hash_or_noop(leaf, n_leaf);
         int n = n_sib < n_bits ? n_sib : n_bits;

@@ -55,14 +55,22 @@ struct ExpandArgs {
     int rb, lookup_bits;
     uint32_t max_cells;        // largest template (cells per record) of the plan: sizes expand_kernel_h's chunk table
     uint32_t *tile_ctr;        // [nproofs] zeroed work counters: tiles are handed out dynamically (null: static striding)
+    uint32_t ntiles = 0, q_tiles = 1;   // expand_fast: work units per proof / per query block (set by launch_expand)
     uint32_t nproofs, roam;    // expand_fast: roam != 0 -> a 1-D grid of resident blocks whose wavefronts move on to the next proof with tiles left (set by launch_expand)
     uint32_t roam_per_cu = 0;  // caller: 0 = one grid column of blocks per proof; k > 0 = roaming wavefronts on (at most) k blocks per CU.  2 fills the
                                // chip (Goldilocks caps: nothing else needs LDS); 1 leaves half of every CU's LDS to the PoseidonBN254 chain kernels of the launches in flight
     ColMap cm;                 // column-major emission (starts == nullptr: flat)
-    // (proof, query) sharding: records of query blocks owned by another rank are skipped (shard_world <= 1: none)
-    uint64_t q_rec0_first, q_rec0_rest, q_nrec_rest; uint32_t nq, shard_rank, shard_world;
+    // (proof, query) sharding (shard_world <= 1: none): the expansion kernel walks only the record ranges of the blocks this rank owns - the
+    // prologue block of proof p (records [0, pro_nrec)) if p % world == rank, query block q (records [q_rec0(q), + q_nrec(q))) if
+    // (p * nq + q) % world == rank; shard_compact: the blocks go to the rank's packed buffer (batchargs.h ShardMap)
+    uint32_t nq, shard_rank, shard_world, shard_compact;
+    uint64_t pro_nrec, q_rec0_first, q_rec0_rest, q_nrec_first, q_nrec_rest, pro_ncell, q_cell0_first, q_cell0_rest, q_ncell_rest, q_slot;
 };
-void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
+int launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream);
+inline void expand_unsharded(ExpandArgs &A) {      // one block per proof: all of its records
+    A.nq = 1; A.shard_rank = 0; A.shard_world = 1; A.shard_compact = 0; A.pro_nrec = A.nrec; A.q_rec0_first = A.q_rec0_rest = ~0ull; A.q_nrec_first = A.q_nrec_rest = 1;
+    A.pro_ncell = A.q_cell0_first = A.q_cell0_rest = A.q_ncell_rest = A.q_slot = 0;
+}
 
 constexpr int MAX_SLOTS = 1536;   // limits of a plan's template table (the default expansion kernel sizes its LDS copy dynamically)
 constexpr int MAX_CONSTS = 96;

@@ -3,9 +3,18 @@
 // CoopSink: one 64-lane wavefront executes one strand of verifier.h *wave-uniformly* (every lane runs the same
 // gadget code on the same values; lane 0 alone writes records / direct cells), and the lanes split up the one
 // wide thing in it: the Goldilocks Poseidon permutation (hash/poseidon/permutation.rs:43-284), 12 lanes = the 12
-// state elements / MDS rows, state exchanged through LDS.  It emits exactly the 2,604 records the sequential
-// template code (chips.h PoseidonPermutationChip) emits, at the same indices — tests/test_gpu_batch.py compares
-// the resulting advice with the oracle byte for byte.
+// state elements / MDS rows.
+//
+// A strand's sponge is a serial chain of permutations, but only in its VALUES: the 2,604 block records of a permutation
+// are a function of its input state alone.  So the strand kernels run in two phases:
+//   values (CoopSinkT<COLS, true>)  the strand's wavefront computes each permutation's output with the state spread over 12
+//                                   lanes (no records, no LDS exchange: broadcasts are v_readlane, the one cross-lane sum of a
+//                                   partial round is a DPP row scan) and appends {record index, input state} to the proof's
+//                                   permutation list;
+//   records (k_glp_emit)            one wavefront per LISTED permutation replays it and writes its records - every permutation
+//                                   of every strand of the launch side by side (CoopSinkT<COLS, false>::coop_poseidon_permute).
+// Together they emit exactly the records the sequential template code (chips.h PoseidonPermutationChip) emits, at the same
+// indices — tests/test_gpu_batch.py compares the resulting advice with the oracle byte for byte.
 #pragma once
 #include "valbackend.h"
 
@@ -27,6 +36,7 @@ __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)
 // ds_read (a namespace-scope __shared__ array keeps the LDS address space; a pointer member would decay to flat).
 __shared__ uint64_t s_glp_k[GLP_CONST_WORDS];
 __shared__ uint64_t s_glp_a[SPONGE_WIDTH], s_glp_b[SPONGE_WIDTH];      // the permutation's state exchange buffers
+__shared__ uint64_t s_glp_m[SPONGE_WIDTH * SPONGE_WIDTH];              // MDS as a dense matrix, row-major: M[r][j] = circ[(j - r) mod 12] + [j == r] diag[r]  (values phase)
 // LDS pointers are handed to the (out-of-line) permutation through the sink: a __shared__ array that several kernels use is reached
 // from a non-kernel function through llvm.amdgcn.lds.offset.table - a GLOBAL load of the offset at every use, i.e. a vmcnt(0) wait
 // for every record store in flight, inside the round loops (that was 60 of the 89 us of a permutation).  A kernel knows the
@@ -37,7 +47,17 @@ static_assert(KO_VS + 242 == GLP_CONST_WORDS, "Goldilocks constant block layout"
 __device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k, int tid, int nthreads) {
     const uint64_t *src = reinterpret_cast<const uint64_t *>(k);
     for (int i = tid; i < GLP_CONST_WORDS; i += nthreads) s_glp_k[i] = g_load_u64(src + i);
+    for (int i = tid; i < SPONGE_WIDTH * SPONGE_WIDTH; i += nthreads) {
+        const int r = i / SPONGE_WIDTH, j = i % SPONGE_WIDTH; int d = j - r; if (d < 0) d += SPONGE_WIDTH;
+        const uint64_t c = g_load_u64(src + KO_CIRC + d);
+        s_glp_m[i] = j == r ? gl_reduce128((u128)c + g_load_u64(src + KO_DIAG + r)) : c;      // (c + diag) v = c v + diag v in the field
+    }
     __syncthreads();
+}
+// plonky2's MDS entries are tiny (<= 41): a row is then two 64-bit sums of 32-bit halves and ONE reduction (the prover's trick, prover.hip)
+inline bool glp_small_mds(const h2w_poseidon_consts_t &k) {
+    for (int i = 0; i < SPONGE_WIDTH; i++) if (k.mds_circ[i] >= (1ull << 27) || k.mds_diag[i] >= (1ull << 27)) return false;
+    return true;
 }
 
 __device__ __forceinline__ uint64_t gl_add_c(uint64_t x, uint64_t y) {   // canonical x + y mod p
@@ -47,11 +67,69 @@ __device__ __forceinline__ uint64_t gl_add_c(uint64_t x, uint64_t y) {   // cano
 }
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) { return __shfl_up(v, d, 64); }
 
-template <bool COLS> struct CoopSinkT {
-    static constexpr bool kCoop = true, kSplitOnly = false;
-    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; int dbg_skip_perm = 0; ColPolicy<COLS> cc;
-    lds64_t *lk = nullptr, *la = nullptr, *lb = nullptr;      // s_glp_k, s_glp_a, s_glp_b of the running kernel (set by bind_lds)
-    __device__ __forceinline__ void bind_lds() { lk = (lds64_t *)s_glp_k; la = (lds64_t *)s_glp_a; lb = (lds64_t *)s_glp_b; }
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {      // src: wave-uniform
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int N> __device__ __forceinline__ uint64_t row_shr64(uint64_t v) {      // lane i <- lane i - N of its 16-lane row, 0 where there is none
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x110 + N, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x110 + N, 0xf, 0xf, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t gl_sbox7(uint64_t x) { const uint64_t x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x6 = gl_mul(x4, x2); return gl_mul(x6, x); }
+// Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES: lane l < 12 holds state element l and
+// returns its element of the output.  K: the constant block in LDS, M: the dense MDS rows (stage_glp_consts).
+__device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64_t *M, int l, bool small) {
+    const int lc = l < SPONGE_WIDTH ? l : SPONGE_WIDTH - 1, lm = lc > 0 ? lc - 1 : 0;
+    auto full_round = [&](int rc) {
+        x = gl_sbox7(gl_add(x, K[KO_ARC + SPONGE_WIDTH * rc + lc]));
+        if (small) {
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < SPONGE_WIDTH; j++) { const uint64_t sj = readlane64(x, j); const uint32_t m = (uint32_t)M[lc * SPONGE_WIDTH + j]; lo += (uint64_t)m * (uint32_t)sj; hi += (uint64_t)m * (uint32_t)(sj >> 32); }
+            x = gl_reduce128((u128)lo + ((u128)hi << 32));
+        } else {
+            uint64_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < SPONGE_WIDTH; j++) acc = gl_muladd(M[lc * SPONGE_WIDTH + j], readlane64(x, j), acc);
+            x = acc;
+        }
+    };
+#pragma unroll 1
+    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(i);
+    x = gl_add(x, K[KO_FIRST + lc]);                                                     // partial_first_constant_layer
+    {   // mds_partial_layer_init: element 0 stays, element c >= 1 = sum_r init[r-1][c-1] s_r
+        uint64_t res = 0;
+#pragma unroll
+        for (int r = 1; r < SPONGE_WIDTH; r++) res = gl_muladd(K[KO_INIT + (r - 1) * 11 + lm], readlane64(x, r), res);
+        x = l == 0 ? x : res;
+    }
+#pragma unroll 1
+    for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
+        const uint64_t y = gl_add(gl_sbox7(x), K[KO_PRC + r]);                            // (lane 0's is the one that counts)
+        const uint64_t s0 = readlane64(y, 0);
+        // d = (circ0 + diag0) s0 + sum_i w_hat_i s_i: one product per lane, summed by a row scan
+        const uint64_t t = l == 0 ? K[KO_CIRC] + K[KO_DIAG] : K[KO_WHAT + r * 11 + lm];
+        uint64_t term = gl_mul(t, l == 0 ? s0 : x); if (l >= SPONGE_WIDTH) term = 0;
+        term = gl_add_c(term, row_shr64<1>(term)); term = gl_add_c(term, row_shr64<2>(term));
+        term = gl_add_c(term, row_shr64<4>(term)); term = gl_add_c(term, row_shr64<8>(term));
+        const uint64_t d = readlane64(term, SPONGE_WIDTH - 1);
+        const uint64_t nx = gl_muladd(K[KO_VS + r * 11 + lm], s0, x);
+        x = l == 0 ? d : nx;
+    }
+#pragma unroll 1
+    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + i);
+    return x;
+}
+constexpr int GLP_LIST_WORDS = 1 + SPONGE_WIDTH;            // one listed permutation: {index of its first record, input state}
+
+// VALPH: the values phase of a strand (see the top of the file); false: the record-emitting permutation (k_glp_emit)
+template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
+    static constexpr bool kCoop = true, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = HASH_MODE;
+    rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; ColPolicy<COLS> cc;
+    lds64_t *lk = nullptr, *la = nullptr, *lb = nullptr, *lm = nullptr;      // s_glp_k, s_glp_a, s_glp_b, s_glp_m of the running kernel (set by bind_lds)
+    uint64_t *glp = nullptr; uint32_t glp_slot = 0; bool small_mds = false;   // values phase: this proof's permutation list, the next slot of this strand
+    __device__ __forceinline__ void bind_lds() { lk = (lds64_t *)s_glp_k; la = (lds64_t *)s_glp_a; lb = (lds64_t *)s_glp_b; lm = (lds64_t *)s_glp_m; }
     bool emit = true;            // false: values only (a sharded run computes every prologue for its challenges, but only the owning rank emits it)
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (lane == 0 && emit) g_store_rec(recs + nrec, a, b, c, d);
@@ -73,6 +151,7 @@ template <bool COLS> struct CoopSinkT {
     __device__ void query_end(int, uint64_t) {}
     __device__ void bn_perm_begin(bool) {}
     __device__ void bn_perm_end(bool) {}
+    __device__ void glp_note() {}
     __device__ void note_load(uint64_t, int) {}
     __device__ bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
     // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
@@ -94,13 +173,23 @@ template <bool COLS> struct CoopSinkT {
     }
 
     __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
-        lds64_t *const K = lk, *const s_a = la, *const s_b = lb;      // (by value: one read of the sink object per call)
-        rec_t *R = recs + nrec;
-        if (dbg_skip_perm) {   // timing-only diagnostic (H2W_DBG_SKIP_PERM=1): advance the counters, skip the arithmetic
-            const uint64_t nG0 = ncells[T_GLOP], nKA0 = ncells[T_KA_GLOP];
-            nrec += GLP_RECS; cell_off += 2 * HALF_N_FULL_ROUNDS * (12 * nKA0 + 48 * nG0 + 12 + 12 * (1 + 13 * nKA0)) + 12 * nKA0 + 12 + 121 * nKA0 + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG0 + nKA0 + nKA0 + 11 * nKA0 + 12 + 11 * nKA0);
+        if constexpr (VALPH) {
+            // values phase: list the permutation (lane 0: where its records start; lanes 1..12: the input state), compute its output
+            uint64_t w = nrec, x = 0;
+#pragma unroll
+            for (int i = 0; i < SPONGE_WIDTH; i++) { if (lane == i + 1) w = st[i]; if (lane == i) x = st[i]; }
+            if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
+            glp_slot++;
+            x = glp_permute_lanes(x, lk, lm, lane, small_mds);
+#pragma unroll
+            for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = readlane64(x, i);
+            const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
+            nrec += GLP_RECS;
+            cell_off += 2 * HALF_N_FULL_ROUNDS * (12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA)) + 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
             return;
         }
+        lds64_t *const K = lk, *const s_a = la, *const s_b = lb;      // (by value: one read of the sink object per call)
+        rec_t *R = recs + nrec;
         const int l = lane, grp13 = lane / 13, idx13 = lane % 13;
         const bool em = emit;
         auto W = [&](int idx, uint64_t A, uint64_t B, uint64_t C) { if (em) g_store_rec(R + idx, A, B, C, 0); };
@@ -209,12 +298,20 @@ template <bool COLS> struct CoopSinkT {
         nrec += GLP_RECS; cell_off += 2 * HALF_N_FULL_ROUNDS * full_cells + part_cells;
     }
 };
-typedef CoopSinkT<false> CoopSink;
 
 // ---------------------------------------------------------------------------------------------------------------
-// QuadSink: four adjacent lanes execute one PoseidonBN254 Merkle chain strand quad-uniformly (lane 0 of the quad writes the
-// strand's few direct cells) and split the width-4 state between them: lane i owns state element i.  The permutation's 4,032
-// cells (hash/poseidon_bn254/permutation.rs:48-203) are emitted by the quad itself while it computes them.
+// QuadSink: four adjacent lanes execute a PoseidonBN254 Merkle chain strand quad-uniformly (lane 0 of the quad writes the
+// strand's few direct cells) and split the width-4 state between them: lane i owns state element i.
+//
+// A Merkle path is a serial chain of permutations (merkle/mod.rs:57-78) only in its VALUES; the 4,032 cells of a permutation
+// (hash/poseidon_bn254/permutation.rs:48-203) are a function of its input state.  Two phases, like the Goldilocks sponge above:
+//   QUAD_VALUES  k_merkle_bn_values: one quad per strand walks the chain on values alone (Montgomery-form state, x^5 in three
+//                products: 282 dependent wavefront-level products per permutation instead of the emitter's 352, no staging, no
+//                stores but the 128-byte output state of each permutation unit);
+//   QUAD_EMIT    k_merkle_bn_emit: one quad per permutation UNIT of every strand - all levels of all paths side by side.  The
+//                quad walks its strand's (cheap) control flow, takes the state its unit starts from out of the values phase's
+//                buffer, and emits the cells of its window: the direct cells in front of its unit (selects, limb sums) and the
+//                permutation's 4,032 cells, computed and streamed by the quad itself as described below.
 //
 // Memory behaviour (what the round-1 emitter stalled on, profiles/r01_pmc_issue_*):
 //   * the PoseidonBN254 tables (canonical for the cells and the adds, pre-multiplied by R for the products) are a per-PLAN device
@@ -236,6 +333,7 @@ constexpr int QUAD_BLOCK = H2W_QUAD_BLOCK;                   // threads per bloc
 constexpr int QUAD_WAVES = QUAD_BLOCK / 64;
 struct __attribute__((aligned(16))) sq16_t { unsigned long long x, y; };
 enum { BK_C = 0, BK_S = 88, BK_M = 88 + 392, BK_P = 88 + 392 + 16, BK_N = 88 + 392 + 32, BK_ZERO = BK_N, BK_ONE = BK_N + 1, BK_T = BK_N + 2 };
+constexpr int BN_PERM_CELLS = 4032;                         // cells of one permutation (20 + 1,100 + 2,912), without the Context's one cached load_zero cell
 constexpr int BN_NSLOT = 20;                                 // value slots per quad (the widest layer, a full-round mix, stages 4 inputs + 16 partial sums)
 constexpr int BN_SLOT_SQ = 16 * 2;                           // 16-byte units per slot row: 16 quads x 32 B
 __shared__ sq16_t s_bn_tab[2 * BK_T * 2];                    // [form][entry][half]: 32.9 KB
@@ -314,14 +412,20 @@ constexpr BnSrc bn_map_partial(int c) {
     return (i == 0 || i == 2) ? bA(4 + k - 1) : i == 1 ? bV(k) : i == 3 ? bV(7) : bV(12 + k - 1);
 }
 
-template <bool COLS> struct QuadSinkT {
-    static constexpr bool kCoop = false, kSplitOnly = false;
+enum { QUAD_VALUES = 1, QUAD_EMIT = 2 };
+template <bool COLS, int MODE> struct QuadSinkT {
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = true; static constexpr int kHashMode = 1;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4; ColPolicy<COLS> cc;
+    fr_t *ustate;                  // output states of this strand's permutation units, [unit][4] (written by QUAD_VALUES, read by QUAD_EMIT)
+    int unit_local = 0;            // units of the strand passed so far
+    int my_w = 0, last_w = 0;      // QUAD_EMIT: the unit this quad emits; the strand's last unit (its window also holds the cells behind it)
+    bool act = true;               // QUAD_EMIT: the cursor is inside this quad's window
+    __device__ __forceinline__ void set_window(int w, int n_units) { my_w = w; last_w = n_units > 0 ? n_units - 1 : 0; unit_local = 0; act = w == 0; }
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-        if (l4 == 0) g_store_rec(recs + nrec, a, b, c, d);
+        if (MODE == QUAD_EMIT && l4 == 0 && act) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
-    __device__ __forceinline__ void cell(const fr_t &v) { if (l4 == 0) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (MODE == QUAD_EMIT && l4 == 0 && act) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
     __device__ int coop_lanes() { return 1; }
@@ -336,6 +440,7 @@ template <bool COLS> struct QuadSinkT {
     __device__ void query_end(int, uint64_t) {}
     __device__ void bn_perm_begin(bool) {}
     __device__ void bn_perm_end(bool) {}
+    __device__ void glp_note() {}
     __device__ void note_load(uint64_t, int) {}
     __device__ bool coop_load_proof(const ValCfg &) { return false; }
     __device__ void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
@@ -349,9 +454,6 @@ template <bool COLS> struct QuadSinkT {
         int l;
     };
     static __device__ __forceinline__ void put(const Em &e, int slot, const fr_t &v) {
-#ifdef H2W_DBG_NOPUT      // timing experiment (tools/build_debug_variant.sh): the results are garbage
-        if (e.l >= 0) return;
-#endif
         sq16_t *q = e.val + slot * BN_SLOT_SQ; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]};
     }
     static __device__ __forceinline__ void put_if(const Em &e, bool on, int slot, const fr_t &v) { if (on) put(e, slot, v); }
@@ -364,9 +466,6 @@ template <bool COLS> struct QuadSinkT {
     template <int N, class MapFn> __device__ __forceinline__ void flush_layer(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
         constexpr int NP = (N + 1) / 2;
         const bool hiq = e.l >= 2;
-#ifdef H2W_DBG_NOFLUSH    // timing experiment (tools/build_debug_variant.sh): bookkeeping only, no cell is written
-        if (e.l >= 0) { e.cell0 += (uint64_t)N; e.gdst += (unsigned long long)N * 32; return; }
-#endif
         if constexpr (COLS) {
             if (cc.hi - e.cell0 < (uint64_t)N || e.cell0 < cc.lo) { flush_layer_cols<N>(e, map, baseA, baseB); return; }
         }
@@ -434,8 +533,73 @@ template <bool COLS> struct QuadSinkT {
         const BnSrc s = map(c);
         return s.kind == 0 ? e.val + s.idx * BN_SLOT_SQ + (e.l & 1) : s.kind == 1 ? e.tabh + s.idx * 2 : s.kind == 2 ? baseA + s.idx * 2 : baseB + s.idx * 2;
     }
+    // One permutation unit of the strand (PoseidonBN254PermutationChip::permute, hash/poseidon_bn254/permutation.rs:190-203).
+    __device__ __forceinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
+        if constexpr (MODE == QUAD_VALUES) { bn_values(st, cfg); unit_local++; return true; }
+        else {
+            const int k = unit_local++;
+            if (k == my_w) bn_emit_cells(st, cfg, zc_ref);
+            else {
+                if (k + 1 == my_w) {              // the state this quad's unit starts from: the output of the unit before it
+                    const fr_t *u = ustate + (uint64_t)k * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) st[i] = g_load_fr(u + i);
+                }
+                if (!zc_ref) { cell_off += 1; zc_ref = true; }      // (the Context's first load_zero cell sits in that unit's first mix)
+                cell_off += BN_PERM_CELLS;
+            }
+            const int cur = unit_local < last_w ? unit_local : last_w;
+            act = cur == my_w;
+            return true;
+        }
+    }
+    // values phase: Montgomery-form state, lane l owns element l.  x^5 = three products; a partial round = four wavefront-level
+    // products (lanes 1-3 form their terms of the sparse row beside lane 0's first S-box product; the column update and S_0 s0' share
+    // the last one); a full round = 3 + 4.  The output state (canonical) goes to the strand's unit buffer.
+    __device__ __noinline__ void bn_values(fr_t *st, const ValCfg &cfg) {
+        const int l = l4, lm = l > 0 ? l - 1 : 0; const uint64_t ninv = cfg.P.ninv;
+        fr_t S = fr_mont_mul(fr_sel(l < 2, fr_sel(l == 0, st[0], st[1]), fr_sel(l == 2, st[2], st[3])), cfg.P.r2, ninv);
+        auto sbox = [&]() { const fr_t X2 = fr_mont_mul(S, S, ninv), X4 = fr_mont_mul(X2, X2, ninv); S = fr_mont_mul(X4, S, ninv); };
+        auto mix = [&](int mb) {
+            const fr_t s0 = quad_bcast<0>(S), s1 = quad_bcast<1>(S), s2 = quad_bcast<2>(S), s3 = quad_bcast<3>(S);
+            fr_t acc = fr_mont_mul(s0, bnk(1, mb + l), ninv);
+            acc = fr_add(fr_mont_mul(s1, bnk(1, mb + 4 + l), ninv), acc);
+            acc = fr_add(fr_mont_mul(s2, bnk(1, mb + 8 + l), ninv), acc);
+            S = fr_add(fr_mont_mul(s3, bnk(1, mb + 12 + l), ninv), acc);
+        };
+        S = fr_add(S, bnk(1, BK_C + l));
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            if (half == 1) {
+#pragma unroll 1
+                for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                    const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                    const fr_t ksxm = bnk(1, ix + l);
+                    const fr_t A_ = fr_mont_mul(S, fr_sel(l == 0, S, ksxm), ninv);        // lane 0: s0^2 | lanes j: S_j s_j
+                    const fr_t X4 = fr_mont_mul(A_, A_, ninv);
+                    const fr_t s0n = fr_add(fr_mont_mul(X4, S, ninv), bnk(1, ic));         // lane 0: s0' = s0^5 + c
+                    const fr_t s0 = quad_bcast<0>(s0n);
+                    const fr_t E_ = fr_mont_mul(s0, fr_sel(l == 0, ksxm, bnk(1, ix + BN_WIDTH + lm)), ninv);      // lane 0: S_0 s0' | lanes k: S'_k s0'
+                    fr_t incl = fr_sel(l == 0, E_, A_);
+                    { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
+                    { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
+                    S = fr_sel(l > 0, fr_add(E_, S), quad_bcast<3>(incl));
+                }
+            }
+#pragma unroll 1
+            for (int r = 0; r < BN_FULL_ROUNDS / 2; r++) {
+                const bool last = r == BN_FULL_ROUNDS / 2 - 1;
+                sbox();
+                if (!(half == 1 && last)) S = fr_add(S, bnk(1, BK_C + (half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH) + l));
+                mix(half == 0 && last ? BK_P : BK_M);
+            }
+        }
+        const fr_t s = fr_mont_mul(S, fr_from_u64(1), ninv);                               // back to canonical
+        g_store_fr(ustate + (uint64_t)unit_local * 4 + l, s);
+        st[0] = quad_bcast<0>(s); st[1] = quad_bcast<1>(s); st[2] = quad_bcast<2>(s); st[3] = quad_bcast<3>(s);
+    }
     // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself.
-    __device__ __noinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
+    __device__ __noinline__ void bn_emit_cells(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
         bool zc = zc_ref;                      // by value: a reference would be re-read with a flat load (vmcnt(0)) at every mix
         const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
         Em e; e.l = l;
@@ -530,9 +694,7 @@ template <bool COLS> struct QuadSinkT {
         }
         st[0] = quad_bcast<0>(s); st[1] = quad_bcast<1>(s); st[2] = quad_bcast<2>(s); st[3] = quad_bcast<3>(s);
         cell_off = e.cell0; zc_ref = zc;
-        return true;
     }
 };
-typedef QuadSinkT<false> QuadSink;
 
 }  // namespace h2w

@@ -444,8 +444,8 @@ static int ensure_expanded(h2w_ctx *c) {
     A.meta = (const uint64_t *)c->d_meta; A.recs = (const rec_t *)c->d_recs; A.nrec = nrec; A.rec_stride = nrec;
     A.out = (fr_t *)c->d_out; A.cell_stride = c->ncells; A.pool = (const fr_t *)c->d_pool;
     c->dt.fill(A); A.rb = c->tt.rb;
-    A.tile_ctr = nullptr; A.cm.starts = nullptr; A.cm.ncols = 0; A.cm.k = 0; A.shard_world = 1; A.shard_rank = 0; A.nq = 1; A.q_rec0_first = A.q_rec0_rest = ~0ull; A.q_nrec_rest = 1;
-    launch_expand(A, 1, 2048, nullptr);
+    A.tile_ctr = nullptr; A.cm.starts = nullptr; A.cm.ncols = 0; A.cm.k = 0; expand_unsharded(A);
+    if (launch_expand(A, 1, 2048, nullptr) != 0) return -1;
     H2W_HIP(hipGetLastError());
     H2W_HIP(hipDeviceSynchronize());
     return 0;

@@ -239,6 +239,36 @@ constexpr int FAST_CH = 8;                                  // virtual cells per
 #endif
 constexpr int FAST_K = H2W_FAST_K;                          // 64-record rows per fetch of a wavefront (its work unit: 256 records)
 constexpr int FAST_T = H2W_FAST_T;                          // records per pass of a wavefront (LDS per block scales with it: 73 KB at 16)
+// Work unit `tile` of a proof -> its records [rbeg, rend) and the pointer its cells' in-proof offsets are added to.  Unsharded: the proof is
+// one block of nrec records.  Sharded: the units walk the blocks this rank owns - the prologue block first (if owned), then
+// the owned query blocks q0, q0 + world, ... - so a rank streams 1 / world of the records and nothing else (tiles past its last
+// block: false).
+constexpr uint32_t FAST_TR = 64 * FAST_K;
+__device__ __forceinline__ bool fast_tile_range(const ExpandArgs &A, uint64_t proof, uint32_t tile, uint32_t q_tiles, uint64_t &rbeg, uint64_t &rend, fr_t *&outp) {
+    outp = A.out + proof * A.cell_stride;
+    if (A.shard_world <= 1) { rbeg = (uint64_t)tile * FAST_TR; rend = rbeg + FAST_TR < A.nrec ? rbeg + FAST_TR : A.nrec; return rbeg < A.nrec; }
+    const uint64_t W = A.shard_world, r = A.shard_rank, u0 = proof * A.nq;
+    const bool own_pro = proof % W == r;
+    const uint32_t tp = own_pro ? (uint32_t)((A.pro_nrec + FAST_TR - 1) / FAST_TR) : 0u;
+    const uint64_t units_before = (u0 + W - 1 - r) / W;
+    uint64_t local = ((proof + W - 1 - r) / W) * A.pro_ncell + units_before * A.q_slot;      // the rank's packed buffer: owned blocks before this proof
+    if (tile < tp) {
+        rbeg = (uint64_t)tile * FAST_TR; rend = rbeg + FAST_TR < A.pro_nrec ? rbeg + FAST_TR : A.pro_nrec;
+        if (A.shard_compact) outp = A.out + local;
+        return true;
+    }
+    const uint32_t t2 = tile - tp, j = t2 / q_tiles, tt = t2 % q_tiles;
+    const uint64_t q = (r + W - u0 % W) % W + (uint64_t)j * W;                                   // this rank's j-th query of the proof
+    if (q >= A.nq) return false;
+    const uint64_t b0 = q == 0 ? A.q_rec0_first : A.q_rec0_rest + (q - 1) * A.q_nrec_rest, bn = q == 0 ? A.q_nrec_first : A.q_nrec_rest;
+    rbeg = b0 + (uint64_t)tt * FAST_TR; rend = rbeg + FAST_TR < b0 + bn ? rbeg + FAST_TR : b0 + bn;
+    if (rbeg >= rend) return false;
+    if (A.shard_compact) {
+        local += (own_pro ? A.pro_ncell : 0) + (uint64_t)j * A.q_slot;
+        outp = A.out + local - (q == 0 ? A.q_cell0_first : A.q_cell0_rest + (q - 1) * A.q_ncell_rest);
+    }
+    return true;
+}
 template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
     typedef FastMap<L> M;
     constexpr int NCH = (M::VT + FAST_CH - 1) / FAST_CH;
@@ -252,7 +282,7 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
     // the first proofs are done and ramp up again: 5.5-5.8 TB/s for a launch alone against 6.3 with every block resident from the start
     // (profiles/r02_expand_grid.txt).
     uint64_t proof = ROAM ? (uint64_t)((blockIdx.x * (EXPAND_THREADS / 64) + wv) % A.nproofs) : (uint64_t)blockIdx.y;
-    const uint32_t ntiles = (uint32_t)((A.nrec + 64 * FAST_K - 1) / (64 * FAST_K));      // work units a wavefront takes from its proof's counter
+    const uint32_t ntiles = A.ntiles, q_tiles = A.q_tiles;      // work units a wavefront takes from its proof's counter (sharded: an upper bound; the units past a proof's last owned block are empty)
     // -2^RB mod r (the one 254-bit constant of check_less_than): limbs of r with bit RB taken out of limb 1 (no borrow)
     const ull neg0 = H2W_FR_M0, neg1 = H2W_FR_M1 - (1ull << (M::RB - 64)), neg2 = H2W_FR_M2, neg3 = H2W_FR_M3;
     unsigned char *my_row = &s_tile[wv][(lane & (FAST_T - 1)) * ROW];
@@ -265,29 +295,30 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
 
   for (;;) {
     const rec_t *recs = A.recs + proof * A.rec_stride;
-    unsigned char *outb = reinterpret_cast<unsigned char *>(A.out + proof * A.cell_stride);
-    unsigned char *const out_half = outb + (hi ? 16 : 0);
     uint32_t tile;
     { uint32_t t0 = 0; if (lane == 0) t0 = atomicAdd(&A.tile_ctr[proof], 1u); tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0); }
     while (tile < ntiles) {
         uint32_t nxt = 0; if (lane == 0) nxt = atomicAdd(&A.tile_ctr[proof], 1u);       // next tile: requested now, read at the bottom
+        uint64_t sbase, rend; fr_t *outp;
+        if (!fast_tile_range(A, proof, tile, q_tiles, sbase, rend, outp)) { tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt); continue; }
+        unsigned char *outb = reinterpret_cast<unsigned char *>(outp);
+        unsigned char *const out_half = outb + (hi ? 16 : 0);
         // The records of FAST_K * 64 consecutive records in one fetch, one record (+ meta) per lane and 64-record row; the passes take theirs
         // from those registers with cross-lane reads.  Loads and stores retire in order on this family, so every vector load a wavefront
         // consumes costs it a wait for all the cell stores it has in flight: one such wait per 16 passes instead of one per pass
         // (profiles/r02_expand_grid.txt: a timing build without the per-pass loads ran the whole job 9 % faster).
-        const uint64_t sbase = (uint64_t)tile * (64 * FAST_K);
         uint64_t mk[FAST_K]; rec_t rk[FAST_K];
 #pragma unroll
         for (int j = 0; j < FAST_K; j++) {
             const uint64_t r = sbase + (uint64_t)j * 64 + (uint64_t)lane;
             mk[j] = 0; rk[j].a = rk[j].b = rk[j].c = rk[j].d = 0;
-            if (r < A.nrec) { mk[j] = A.meta[r]; rk[j] = recs[r]; }
+            if (r < rend) { mk[j] = A.meta[r]; rk[j] = recs[r]; }
         }
 #pragma unroll 1
         for (int pass = 0; pass < FAST_K * (64 / FAST_T); pass++) {
             const int fj = pass / (64 / FAST_T), fq = pass % (64 / FAST_T);
             const uint64_t r0 = sbase + (uint64_t)fj * 64 + (uint64_t)fq * FAST_T;
-            if (r0 >= A.nrec) break;
+            if (r0 >= rend) break;
             uint64_t cm = mk[0]; rec_t cr = rk[0];
 #pragma unroll
             for (int j = 1; j < FAST_K; j++) if (fj == j) { cm = mk[j]; cr.a = rk[j].a; cr.b = rk[j].b; cr.c = rk[j].c; cr.d = rk[j].d; }      // (wave-uniform selects)
@@ -295,14 +326,7 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
             const uint64_t pm = __shfl((unsigned long long)cm, src, 64);
             rec_t prc; prc.a = __shfl((unsigned long long)cr.a, src, 64); prc.b = __shfl((unsigned long long)cr.b, src, 64);
             prc.c = __shfl((unsigned long long)cr.c, src, 64); prc.d = __shfl((unsigned long long)cr.d, src, 64);
-            bool mine = lane < FAST_T && r0 + (uint64_t)lane < A.nrec;
-            if (mine && A.shard_world > 1) {              // unit = (proof, query), round-robin; the prologue block belongs to rank proof mod world
-                const uint64_t r = r0 + lane;
-                if (r >= A.q_rec0_first) {
-                    const uint64_t q = r < A.q_rec0_rest ? 0 : 1 + (r - A.q_rec0_rest) / A.q_nrec_rest;
-                    mine = (proof * A.nq + q) % A.shard_world == A.shard_rank;
-                } else mine = proof % A.shard_world == A.shard_rank;      // prologue block: the proof's owner
-            }
+            const bool mine = lane < FAST_T && r0 + (uint64_t)lane < rend;
             uint32_t t = T_LITERAL; rec_t rc; rc.a = rc.b = rc.c = rc.d = 0; ull coff = 0;
             if (mine) { rc = prc; t = meta_tmpl(pm); coff = meta_off(pm); }
             // template -> range of virtual cells
@@ -397,22 +421,24 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
 
 // every template id a batched plan emits is fixed (< T_DYNAMIC; dynamic range-check templates and literal runs are eager-context
 // features), so the fast kernel serves the batched path whenever it is instantiated for the plan's lookup_bits
-void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
-    if (A.nrec == 0 || nproofs == 0) return;
+int launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
+    if (A.nrec == 0 || nproofs == 0) return 0;
     const bool fast_ok = A.tile_ctr != nullptr && A.pool == nullptr && A.cm.starts == nullptr && A.ntmpl <= T_DYNAMIC;
     if (fast_ok && (A.lookup_bits == 21 || A.lookup_bits == 13 || A.lookup_bits == 8)) {
-        const uint64_t ntiles = (A.nrec + 64 * FAST_K - 1) / (64 * FAST_K);
-        uint64_t gx = (uint64_t)grid_x; if (gx * (EXPAND_THREADS / 64) > ntiles) gx = (ntiles + EXPAND_THREADS / 64 - 1) / (EXPAND_THREADS / 64); if (gx < 1) gx = 1;
         ExpandArgs B = A; B.nproofs = (uint32_t)nproofs; B.roam = 0;
+        // work units per proof: all of its records, or - sharded - the prologue block plus ceil(nq / world) query blocks (an upper bound per proof)
+        uint64_t ntiles = (A.nrec + FAST_TR - 1) / FAST_TR;
+        if (A.shard_world > 1) {
+            const uint64_t qn = A.q_nrec_first > A.q_nrec_rest ? A.q_nrec_first : A.q_nrec_rest;
+            B.q_tiles = (uint32_t)((qn + FAST_TR - 1) / FAST_TR); if (B.q_tiles < 1) B.q_tiles = 1;
+            ntiles = (A.pro_nrec + FAST_TR - 1) / FAST_TR + (uint64_t)B.q_tiles * ((A.nq + A.shard_world - 1) / A.shard_world);
+        }
+        B.ntiles = (uint32_t)ntiles;
+        uint64_t gx = (uint64_t)grid_x; if (gx * (EXPAND_THREADS / 64) > ntiles) gx = (ntiles + EXPAND_THREADS / 64 - 1) / (EXPAND_THREADS / 64); if (gx < 1) gx = 1;
         dim3 grid((unsigned)gx, (unsigned)nproofs);
         // roaming wavefronts: a batch of proofs with many tiles each (the witness path); many small instances (h2w_chipbatch) keep one column each
         const uint64_t waves = EXPAND_THREADS / 64;
-        bool roam_ok = A.roam_per_cu > 0 && ntiles >= 16 && nproofs <= 4096 && grid_x > 0;
-#ifdef H2W_DEBUG_HOOKS   // timing experiments only (tools/build_debug_variant.sh)
-        { static int no = -1; if (no < 0) { const char *e = getenv("H2W_DBG_NO_ROAM"); no = e ? atoi(e) : 0; } if (no) roam_ok = false; }
-        static int dbg_nb = -1; if (dbg_nb < 0) { const char *e = getenv("H2W_DBG_ROAM_BLOCKS"); dbg_nb = e ? atoi(e) : 0; }      // > 0: roam with that many blocks, whatever the caller allows
-        if (dbg_nb > 0) roam_ok = ntiles >= 16 && nproofs <= 4096;
-#endif
+        const bool roam_ok = A.roam_per_cu > 0 && ntiles >= 16 && nproofs <= 4096 && grid_x > 0;
         if (roam_ok) {
             static int cus[64] = {0}; int dev = 0; (void)hipGetDevice(&dev);
             if (dev >= 0 && dev < 64 && !cus[dev]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus[dev] = n > 0 ? n : 256; }
@@ -422,9 +448,6 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
             uint64_t nb = (uint64_t)ncu * per_cu;
             const uint64_t want = (ntiles * nproofs + waves - 1) / waves; if (nb > want) nb = want;
             if (nb < 1) nb = 1;
-#ifdef H2W_DEBUG_HOOKS
-            if (dbg_nb > 0) nb = (uint64_t)dbg_nb;
-#endif
             B.roam = 1; grid = dim3((unsigned)nb, 1);
         }
         if (B.roam) {
@@ -436,8 +459,9 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
             else if (A.lookup_bits == 13) hipLaunchKernelGGL((expand_fast<13, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
             else hipLaunchKernelGGL((expand_fast<8, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
         }
-        return;
+        return 0;
     }
+    if (A.shard_compact) { set_error("expansion: the packed shard layout needs the fast expansion kernel (flat layout, lookup_bits 21 / 13 / 8)"); return -1; }
     const int TILE_RECS = 32;
     const uint64_t ntiles = (A.nrec + TILE_RECS - 1) / TILE_RECS;
     uint64_t gx = (uint64_t)grid_x; if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
@@ -445,6 +469,7 @@ void launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_
     const size_t dyn = ((size_t)A.nconsts * 32 + (size_t)A.nslots * 4 + 15) & ~(size_t)15;      // expand_kernel_t's tables
     if (A.cm.starts) hipLaunchKernelGGL((expand_kernel_t<32, 5, true>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
     else hipLaunchKernelGGL((expand_kernel_t<32, 5, false>), grid, dim3(EXPAND_THREADS), dyn, stream, A);
+    return 0;
 }
 
 }  // namespace h2w

@@ -16,13 +16,9 @@ namespace h2w {
 
 template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_strands(BatchArgs A) {
     typedef DevSinkT<COLS, true> GlueSink; typedef ValBackend<GlueSink> GlueB;
-    if (A.dbg_prio & 4) __builtin_amdgcn_s_setprio(3);      // (experiment switch: always 0 in the product build)
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nq = A.shape.num_queries;
-    if (idx >= A.nproofs * nq) return;
-    const int p = idx / nq, q = idx % nq;
-    if (!own_unit(A, p, q)) return;
-    GlueSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = A.out + (uint64_t)p * A.cell_stride; sink.ncells = A.ncells; sink.cc.init(A.cm);
+    int p, q;
+    if (!own_unit_at(A, blockIdx.x * blockDim.x + threadIdx.x, p, q)) return;      // lane i of the launch = this rank's i-th (proof, query) unit
+    GlueSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
     const ChallengeBlock<GlueB> &cb = *reinterpret_cast<const ChallengeBlock<GlueB> *>(&A.cbs[p]);
     GlueB be(sink, make_cfg(A, p), true);
@@ -31,7 +27,8 @@ template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) v
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
-void launch_glue_strands(const BatchArgs &A, unsigned nlanes, hipStream_t stream) {
+void launch_glue_strands(const BatchArgs &A, hipStream_t stream) {
+    const unsigned nlanes = A.sh.n_own_units;
     if (A.cm.starts) hipLaunchKernelGGL(k_strands<true>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
     else hipLaunchKernelGGL(k_strands<false>, dim3((nlanes + 63) / 64, 1), dim3(64), 0, stream, A);
 }

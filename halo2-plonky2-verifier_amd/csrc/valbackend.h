@@ -22,6 +22,10 @@ struct StrandTable {
     uint64_t pro_nrec, pro_ncell, total_rec, total_cell;
     // BN254 permutation units (one unit = the 4,032(+1) cells of one PoseidonBN254 permute call)
     uint64_t q_unit0[2], q_nunit[2], mk_unit_rel[2][MK_KINDS], total_unit; int64_t first_zero_unit;
+    uint32_t mk_nunit[MK_KINDS];        // units of a Merkle strand of each kind (the same for every query)
+    uint32_t mk_item0[MK_KINDS + 1];    // emission work items of a query: strand kind k owns items [mk_item0[k], mk_item0[k + 1]) - one per unit, one for a unit-less strand
+    // Goldilocks-Poseidon permutations in stream order (the proof's permutation list): the prologue's, then query by query the Merkle strands' (Goldilocks caps)
+    uint32_t pro_nglp, q_nglp, mk_glp_rel[MK_KINDS], mk_nglp[MK_KINDS], total_glp;
 };
 HF uint64_t strand_q_unit(const StrandTable &t, int q) { return q == 0 ? t.q_unit0[0] : t.q_unit0[1] + (uint64_t)(q - 1) * t.q_nunit[1]; }
 HF uint64_t strand_q_rec(const StrandTable &t, int q) { return q == 0 ? t.q_rec0[0] : t.q_rec0[1] + (uint64_t)(q - 1) * t.q_nrec[1]; }
@@ -45,8 +49,12 @@ template <class Sink> struct ValBackend {
     typedef uint64_t Gl; typedef uint64_t Bool; typedef fr_t Fr; typedef u128 Big;
     static constexpr bool kCoopPoseidon = Sink::kCoop;
     static constexpr bool kSplitOnly = Sink::kSplitOnly;       // the backend only ever runs strands whose Merkle proofs are other strands
+    static constexpr bool kBnUnits = Sink::kBnUnits;           // every PoseidonBN254 permutation of this backend is a unit handled by the sink
+    static constexpr int kHashMode = Sink::kHashMode;          // >= 0: the only hash mode this backend is ever run with (-1: the shape's)
+    HF int md() const { if constexpr (kHashMode >= 0) return kHashMode; else return cfg.mode; }
     Sink &sink; ValCfg cfg; bool zero_cached; uint32_t status; uint64_t unit_idx = 0;
     HF void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *k) { sink.coop_poseidon_permute(st, k); }
+    HF void glp_note() { sink.glp_note(); }      // a Goldilocks-Poseidon permutation starts here (the shape compiler counts them)
     HF ValBackend(Sink &s, const ValCfg &c, bool zero_cached_) : sink(s), cfg(c), zero_cached(zero_cached_), status(0) {}
 
     HF void fail(uint32_t code) { if (!status) status = code; }
@@ -97,11 +105,13 @@ template <class Sink> struct ValBackend {
         G(); cell64(z ? 1 : 0); cell(a); cell(inv); cell64(1); G(); cell64(0); cell(a); cell64(z ? 1 : 0); cell64(0);
         return z ? 1 : 0;
     }
-    HNI void idx_to_indicator(Gl idx, int len, Bool *out) {
+    HNI void idx_to_indicator(Gl idx, int len, Bool *out) {       // out may be null (cells only)
         fr_t iv = fr_from_u64(idx);
         for (int i = 0; i < len; i++) {
-            if (i == 0) out[0] = is_zero_cells(iv);
-            else { fr_t d = fr_sub(iv, fr_from_u64((uint64_t)i)); G(); cell(d); cell64((uint64_t)i); cell64(1); cell(iv); out[i] = is_zero_cells(d); }
+            Bool z;
+            if (i == 0) z = is_zero_cells(iv);
+            else { fr_t d = fr_sub(iv, fr_from_u64((uint64_t)i)); G(); cell(d); cell64((uint64_t)i); cell64(1); cell(iv); z = is_zero_cells(d); }
+            if (out) out[i] = z;
         }
     }
     HNI Gl select_by_indicator(const Gl *a, int stride, const Bool *ind, int len) {   // [0, a0, ind0, s0, ...]
@@ -149,10 +159,10 @@ template <class Sink> struct ValBackend {
         G(); cell(diff); cell64(1); cell(b); cell(a); G(); cell(b); cell64(sel); cell(diff); cell(out);
         return out;
     }
-    HNI Fr fr_select_from_idx(const Fr *col, int n, Gl idx) {
-        Bool ind[MAX_CAP]; idx_to_indicator(idx, n, ind);
+    template <class ColF> HF Fr fr_select_from_idx_fn(int n, ColF col, Gl idx) {      // select_from_idx over col(0..n-1): no indicator / column arrays
+        idx_to_indicator(idx, n, nullptr);
         Fr sum = fr_zero(); if (n > 0) G(); cell64(0);
-        for (int i = 0; i < n; i++) { if (ind[i]) sum = h2w::fr_add(sum, col[i]); cell(col[i]); cell64(ind[i]); if (i + 1 < n) G(); cell(sum); }
+        for (int i = 0; i < n; i++) { const Fr c = col(i); const Bool ind = idx == (uint64_t)i ? 1 : 0; if (ind) sum = h2w::fr_add(sum, c); cell(c); cell64(ind); if (i + 1 < n) G(); cell(sum); }
         return sum;
     }
     HF Fr limbs_to_num(const Gl *in, int n) {             // RangeChip::limbs_to_num(limbs, 64)
@@ -176,7 +186,7 @@ template <class Sink> struct ValBackend {
     HF Gl proof_gl(uint64_t w) { return pw(w); }
     HF HashW<ValBackend> proof_hash(uint64_t w) {
         HashW<ValBackend> h;
-        if (cfg.mode == 0) { for (int i = 0; i < 4; i++) h.e[i] = pw(w + i); h.f = fr_zero(); }
+        if (md() == 0) { for (int i = 0; i < 4; i++) h.e[i] = pw(w + i); h.f = fr_zero(); }
         else { for (int i = 0; i < 4; i++) { h.f.l[i] = pw(w + i); h.e[i] = 0; } }
         return h;
     }
@@ -184,8 +194,8 @@ template <class Sink> struct ValBackend {
     HF void load_proof_gl(uint64_t w) { sink.note_load(w, 0); gl_witness(pw(w)); }
     HF void load_proof_gl_nocheck(uint64_t w) { sink.note_load(w, 1); sink.rec(T_CONST1, pw(w), 0, 0, 0); }
     HF void load_proof_hash(uint64_t w) {
-        sink.note_load(w, cfg.mode == 0 ? 2 : 3);
-        if (cfg.mode == 0) sink.rec(T_CONST4, pw(w), pw(w + 1), pw(w + 2), pw(w + 3));
+        sink.note_load(w, md() == 0 ? 2 : 3);
+        if (md() == 0) sink.rec(T_CONST4, pw(w), pw(w + 1), pw(w + 2), pw(w + 3));
         else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = pw(w + i); cell(v); }
     }
     // ---------------------------------------------------------------- BN254 permutation units
@@ -223,7 +233,7 @@ template <class Sink> struct ValBackend {
 
 // device sink: records into this proof's record array, direct cells into this proof's advice range
 template <bool COLS, bool SPLIT_ONLY = false> struct DevSinkT {
-    static constexpr bool kCoop = false, kSplitOnly = SPLIT_ONLY;
+    static constexpr bool kCoop = false, kSplitOnly = SPLIT_ONLY, kBnUnits = false; static constexpr int kHashMode = -1;
     HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; ColPolicy<COLS> cc;
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }
@@ -237,6 +247,7 @@ template <bool COLS, bool SPLIT_ONLY = false> struct DevSinkT {
     HF void query_end(int, uint64_t) {}
     HF void bn_perm_begin(bool) {}
     HF void bn_perm_end(bool) {}
+    HF void glp_note() {}
     HF void note_load(uint64_t, int) {}
     HF bool coop_load_proof(const ValCfg &) { return false; }
     HF bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }

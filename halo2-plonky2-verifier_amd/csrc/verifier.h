@@ -12,7 +12,7 @@
 namespace h2w {
 
 constexpr int MAX_QUERIES = 128;
-constexpr int CH_BUF = 2 * MAX_FINAL_POLY + 16;
+constexpr int CH_BUF = (5 * MAX_CAP > 2 * MAX_FINAL_POLY ? 5 * MAX_CAP : 2 * MAX_FINAL_POLY) + 16;      // the sponge's input buffer: a cap of BN254 hashes (5 limbs each) or the final polynomial + the PoW witness
 constexpr int MK_KINDS = 3 + MAX_STEPS;   // merkle strand kinds: initial oracle o (0..2), fold step i (3+i)
 
 // wires produced by the prologue and consumed by the query strands (fri/mod.rs:64-69 FriChallengesWire + instance points)
@@ -44,6 +44,25 @@ template <class B> struct ChallengerChip {
     }
     HF ExtW<B> get_extension_challenge() { ExtW<B> r; r.e[0] = get_challenge(); r.e[1] = get_challenge(); return r; }  // :119-126
 };
+
+// index bits of a query as the device Merkle strands see them: bit i of the strand = bit lo + i of the query index (no per-lane array)
+struct PackedBits { uint64_t x; int lo; HF uint64_t operator[](int i) const { return (x >> (lo + i)) & 1; } };
+
+// Limits of a shape, shared by every entry point that takes one (plan compile, the eager StarkChip driver): the chips size their
+// stack arrays by MAX_*; nullptr = fine.
+inline const char *shape_check(const h2w_shape_t &s) {
+    if (s.lookup_bits < 2 || s.lookup_bits > 28) return "lookup_bits outside [2, 28]";
+    if (s.num_queries < 1 || s.num_queries > MAX_QUERIES) return "num_queries outside [1, 128]";
+    if (s.cap_height < 0 || (1 << s.cap_height) > MAX_CAP) return "cap_height outside [0, 6]";
+    if (s.arity_bits < 1 || (1 << s.arity_bits) > MAX_ARITY) return "arity_bits outside [1, 4]";
+    if (s.n_cols < 1 || s.n_perm_z < 0 || s.n_quotient < 1 || s.n_cols + s.n_perm_z + s.n_quotient > MAX_BATCH_POLYS) return "too many / too few committed polynomials";
+    if (s.hash_mode < 0 || s.hash_mode > 1) return "hash_mode must be 0 or 1";
+    if (s.degree_bits < 0 || s.rate_bits < 0 || s.degree_bits + s.rate_bits > 63 || s.degree_bits + s.rate_bits < s.cap_height) return "degree_bits / rate_bits do not fit the cap height or 63 bits";
+    if (s.pow_bits < 0 || s.pow_bits > 63 || s.n_pis < 0 || s.num_challenges < 0 || s.final_poly_bits < 0) return "negative or oversized protocol parameter";
+    if (s.n_perm_z > 0 && s.perm_batch_size < 1) return "perm_batch_size < 1";
+    if (derive_shape(s).final_poly_len > MAX_FINAL_POLY) return "final polynomial too long";
+    return nullptr;
+}
 
 // =========================================================================== the verifier, strand by strand
 template <class B> struct Verifier {
@@ -142,23 +161,23 @@ template <class B> struct Verifier {
         if (s.n_perm_z > 0 && o == 1) return pl.perm_cap;
         return pl.quotient_cap;
     }
-    HF void merkle_strand(int q, int kind, const Bool *bits, int n_bits, Gl cap_index) {
+    // proof words as an indexable view (a leaf is read once, word by word: no per-lane copy of it)
+    struct ProofGl { B *be; uint64_t base; HF Gl operator[](int i) const { return be->proof_gl(base + (uint64_t)i); } };
+    template <class BitsT> HF void merkle_strand(int q, int kind, const BitsT &bits, int n_bits, Gl cap_index) {
         const uint64_t qw = query_word(q);
         if (kind < 3) {
             const int o = kind; const uint64_t base = qw + pl.init_off[o]; const int ne = d.oracle_polys[o];
-            Gl leaf[MAX_BATCH_POLYS]; for (int i = 0; i < ne; i++) leaf[i] = be.proof_gl(base + i);
             const uint64_t capw = initial_cap_word(o), sibw = base + ne;
-            mk.verify_proof_to_cap_with_cap_index(leaf, ne, bits, n_bits, cap_index, d.cap_size,
+            mk.verify_proof_to_cap_with_cap_index(ProofGl{&be, base}, ne, bits, n_bits, cap_index, d.cap_size,
                 [&](int i) { return be.proof_hash(capw + 4ull * i); }, pl.init_sibs, [&](int i) { return be.proof_hash(sibw + 4ull * i); });
         } else {
             const int st = kind - 3; const uint64_t base = qw + pl.step_off[st]; const int ne = 2 << d.arity[st];
-            Gl leaf[2 * MAX_ARITY]; for (int i = 0; i < ne; i++) leaf[i] = be.proof_gl(base + i);
             const uint64_t capw = pl.commit_caps + (uint64_t)st * d.cap_size * 4, sibw = base + ne;
-            mk.verify_proof_to_cap_with_cap_index(leaf, ne, bits, n_bits, cap_index, d.cap_size,
+            mk.verify_proof_to_cap_with_cap_index(ProofGl{&be, base}, ne, bits, n_bits, cap_index, d.cap_size,
                 [&](int i) { return be.proof_hash(capw + 4ull * i); }, pl.step_sibs[st], [&](int i) { return be.proof_hash(sibw + 4ull * i); });
         }
     }
-    HF void merkle_call(int q, int kind, const Bool *bits, int n_bits, Gl cap_index) {
+    template <class BitsT> HF void merkle_call(int q, int kind, const BitsT &bits, int n_bits, Gl cap_index) {
         if constexpr (B::kSplitOnly) { be.merkle_split(q, kind); return; }      // glue strands: the cells of this call belong to a merkle strand
         else {
             if (be.merkle_split(q, kind)) return;

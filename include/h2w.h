@@ -235,13 +235,25 @@ int h2w_check_constraints(h2w_plan *, const void *advice_dev, uint64_t proof_str
                           uint64_t bad[2], void *stream);
 
 /* (proof, query) sharding across the GPUs of a node (north star: "independent FRI queries and Merkle paths sharded across
- * the 8 GPUs"): rank r of `world` generates, at their global offsets in its own advice_dev[n_proofs][num_cells], the prologue
- * block of the proofs it owns (proof % world == r: witness load, challenger, PoW, reduced openings - every rank computes the
- * VALUES of every prologue, it needs the challenges, but only the owner emits the cells) and the query blocks of the units
- * (proof * num_queries + query) % world == r; the other blocks are not touched.  No collective on the data path: every rank
- * needs the proofs (one broadcast) and nothing else.  The ranks' blocks are disjoint and their union is the full stream. */
+ * the 8 GPUs"; the loop being dealt out is fri/mod.rs:488-501): rank r of `world` generates, at their global offsets in its own
+ * advice_dev[n_proofs][num_cells], the prologue block of the proofs it owns (proof % world == r: witness load, challenger, PoW, reduced
+ * openings) and the query blocks of the units (proof * num_queries + query) % world == r; the other blocks are not touched.  A rank
+ * LAUNCHES only what it owns: its strand kernels run over its own units, its expansion kernel walks its own record ranges, so the
+ * chain / glue / expansion time of a rank is 1 / world of the unsharded launch's.  The one exception is the values of the prologues
+ * (one wavefront per proof, a fixed latency whatever the number of proofs): every rank needs every proof's challenges and computes
+ * them itself - cheaper than a collective in the middle of the call; only the owner writes the block.  No collective on the data path:
+ * every rank needs the proofs (one broadcast) and nothing else.  The ranks' blocks are disjoint and their union is the full stream. */
 int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev,
                                 void *stream, int rank, int world);
+/* The same blocks PACKED: shard_advice_dev holds only this rank's blocks, h2w_plan_shard_cells(plan, n_proofs, rank, world) cells, back to
+ * back in (proof, block) order (prologue block first, then the owned query blocks by query number; every query block takes a slot of the
+ * larger of the two query block sizes) - a rank's buffer is 1 / world of the stream, so the batch that fits a GPU grows with the world.
+ * h2w_plan_shard_block: where a block lies - *local_cell in the packed buffer, *n_cells long, *global_cell its offset inside its proof's
+ * flat stream; query < 0: the prologue block.  Returns 1 (and writes nothing) when the block belongs to another rank. */
+uint64_t h2w_plan_shard_cells(const h2w_plan *, uint64_t n_proofs, int rank, int world);
+int h2w_plan_shard_block(const h2w_plan *, int rank, int world, uint64_t proof, int query, uint64_t *local_cell, uint64_t *n_cells, uint64_t *global_cell);
+int h2w_fri_witness_batch_shard_compact(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, void *shard_advice_dev, void *workspace_dev,
+                                        void *stream, int rank, int world);
 /* The block structure of a proof's cell stream that the sharding above follows (static per shape; no device needed):
  * out[0] = cells of the prologue block [0, out[0]); out[1] = cells of query block 0 (it holds the Context's one cached load_zero
  * cell when that falls into a query); out[2] = cells of every later query block; out[3] = cells per proof
@@ -292,10 +304,14 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
 #define H2W_OPT_SERIAL_EXPAND 2
 int h2w_plan_configure(h2w_plan *, int option, int value);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the streams it launches on:
- * ms[0] = prologue strands, ms[1] = query glue strands (+ Goldilocks-Poseidon Merkle strands), ms[2] = PoseidonBN254 Merkle
- * chain kernel (0 with Goldilocks-Poseidon caps), ms[3] = expansion kernel, ms[4] = whole call.
+ * ms[0] = prologue strands (values; with PoseidonBN254 caps also the records of their permutations), ms[1] = query glue strands (with
+ * Goldilocks-Poseidon caps also the Merkle strands' values and the records of every listed permutation), ms[2] = PoseidonBN254 Merkle
+ * chains, values + emission (0 with Goldilocks-Poseidon caps), ms[3] = expansion kernel, ms[4] = whole call.
  * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
 int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
+/* The same per kernel: ms[0] k_prologue_values, ms[1] k_glp_emit (records of the listed Goldilocks-Poseidon permutations), ms[2] k_strands
+ * (+ k_merkle_gl_values), ms[3] k_merkle_bn_values, ms[4] k_merkle_bn_emit, ms[5] expansion kernel, ms[6] whole call, ms[7] = 0. */
+int h2w_plan_timing_ex(h2w_plan *, uint64_t back, float ms[8]);
 int h2w_plan_last_timing(h2w_plan *, float ms[5]);
 /* Elapsed ms from event `which_a` of the batch call `back_a` calls before the last one to event `which_b` of the call `back_b` before
  * the last one (negative when b came first): how the kernels of different calls lie against each other on the device. */

@@ -184,6 +184,65 @@ def test_noncanonical_proof_words_are_flagged(h2w, h2w_api, oracle, consts, mode
 
 
 @pytest.mark.parametrize("mode", [1, 0])
+def test_cap_height_five(h2w, h2w_api, oracle, consts, mode):
+    """A 32-entry Merkle cap (cap_height 5; the reference's standard_fast_config has 4, nothing in it bounds the height): the cap's
+    select_from_idx is 8 + 12 * 31 + 1 + 3 * 32 cells per hash element."""
+    run_batch(h2w, h2w_api, oracle, consts, (7, 2, 1, mode), [91, 92], cap_height=5)
+    run_batch(h2w, h2w_api, oracle, consts, (8, 2, 2, mode), [93], cap_height=6)          # 64 entries, one fold step
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_packed_shard_layout(h2w, h2w_api, oracle, consts, mode):
+    """h2w_fri_witness_batch_shard_compact: a rank's buffer holds only its own blocks, back to back (1 / world of the stream).  Every block
+    of every rank equals the oracle's cells of that block, the ranks' blocks cover every proof exactly once, and nothing is written
+    outside them."""
+    import numpy as np
+    import torch
+    ko, kh = consts
+    sh = h2w.fibonacci_shape(7, 5, rate_bits=2, hash_mode=mode); osh = oracle.fibonacci_shape(7, 5, rate_bits=2, hash_mode=mode)
+    plan = h2w_api.Plan(sh, kh)
+    n, world = 5, 3
+    proofs = [oracle.synth_proof(osh, 140 + i) for i in range(n)]
+    host = torch.empty(n * plan.proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * plan.proof_words:(i + 1) * plan.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    want = []
+    for p in proofs:
+        ctx = oracle.Ctx(21, track_scopes=False)
+        assert oracle.verify_stark(ctx, osh, ko, p) == 0
+        want.append(np.frombuffer(ctx.advice_bytes(), dtype=np.int64).reshape(plan.num_cells, 4)); ctx.close()
+    covered = np.zeros((n, plan.num_cells), dtype=np.int32)
+    total = 0
+    for rank in range(world):
+        cells = plan.shard_cells(n, rank, world); total += cells
+        buf = torch.full((cells + 8, 4), -1, dtype=torch.int64, device="cuda")          # 8 guard cells behind the buffer
+        ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        plan.run_shard_compact(d_proofs.data_ptr(), n, buf.data_ptr(), ws.data_ptr(), rank, world, st)
+        torch.cuda.synchronize()
+        assert plan.status(ws.data_ptr(), n, st) == [0] * n
+        got = buf.cpu().numpy()
+        assert (got[cells:] == -1).all()
+        used = np.zeros(cells, dtype=bool)
+        for p_ in range(n):
+            for q in range(-1, sh.num_queries):
+                blk = plan.shard_block(rank, world, p_, q)
+                owner = (p_ % world) if q < 0 else (p_ * sh.num_queries + q) % world
+                assert (blk is not None) == (owner == rank)
+                if blk is None:
+                    continue
+                lo, cnt, g = blk
+                assert (got[lo:lo + cnt] == want[p_][g:g + cnt]).all(), (rank, p_, q)
+                assert not used[lo:lo + cnt].any(); used[lo:lo + cnt] = True
+                covered[p_, g:g + cnt] += 1
+        assert (got[:cells][~used] == -1).all()              # (slack of a query slot: untouched)
+    assert (covered == 1).all()
+    assert total < n * plan.num_cells + n * sh.num_queries + world          # no more than the stream plus one slack cell per query block
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
 def test_query_sharding_union_is_the_full_stream(h2w, h2w_api, oracle, consts, mode):
     """(proof, query) units dealt round-robin to the ranks, the prologue block of a proof to rank proof mod world (every
     rank still computes every prologue's VALUES: it needs the challenges).  A rank's buffer holds its own blocks only (the rest
