@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fork", action="store_true", help="experiment: PoseidonBN254 chain kernels on the caller's stream (H2W_OPT_FORK_CHAINS = 0)")
     ap.add_argument("--serial-expand", type=int, default=-1, choices=[-1, 0, 1], help="H2W_OPT_SERIAL_EXPAND (-1: the library's default)")
+    ap.add_argument("--chain-passes", type=int, default=0, choices=[0, 1, 2], help="H2W_OPT_CHAIN_PASSES (0: the library's default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -182,6 +183,8 @@ def main():
         plan.configure(OPT_FORK_CHAINS, 0)
     if args.serial_expand >= 0:
         plan.configure(OPT_SERIAL_EXPAND, args.serial_expand)
+    if args.chain_passes:
+        plan.configure(3, args.chain_passes)
 
     cell_bytes = plan.num_cells * 32
     B = args.batch if args.batch > 0 else max(1, min(64, int(58.6e9 // cell_bytes)))
@@ -275,10 +278,11 @@ def main():
 
     # per-kernel timing from the HIP events the library records on the streams it launches on
     # (a) over the timed region (launches overlap each other there, so these intervals include time-sharing);
-    keys = ("prologue", "glue_strands" if hash_mode == 1 else "glue_and_merkle_strands", "merkle_chains", "expand", "launch")
+    keys = ("prologue_values", "perm_records", "glue_strands" if hash_mode == 1 else "glue_and_merkle_strands", "chain_values", "chain_emit", "expand", "launch")
+    NK = len(keys)
     nback = min(args.steps * R, 64)
-    tim = [plan.timing(i) for i in range(nback)]
-    overl = [sum(t[k] for t in tim) / nback for k in range(5)]
+    tim = [plan.timing_ex(i) for i in range(nback)]
+    overl = [sum(t[k] for t in tim) / nback for k in range(NK)]
     # how the expansion kernels of successive launches lie against each other (H2W_EV_EXPAND_START = 6, _END = 7): the gap from the
     # end of one to the start of the next (negative = they overlapped) and the spacing of their ends = the steady-state launch period
     ng = min(nback - 1, 24)
@@ -296,9 +300,9 @@ def main():
             torch.cuda.synchronize()
             launch(0)
             torch.cuda.synchronize()
-            iso.append(plan.timing(0))
+            iso.append(plan.timing_ex(0))
         iso = iso[1:]
-        isol = [sum(t[k] for t in iso) / len(iso) for k in range(5)]
+        isol = [sum(t[k] for t in iso) / len(iso) for k in range(NK)]
         plan.configure(OPT_FORK_CHAINS, 0 if args.no_fork else 1)
     # (c) the expansion kernel with its launches back to back on the bench's streams (h2w_fri_expand_records: expansion only),
     #     three rounds over all streams; aggregate bytes / wall time
@@ -321,14 +325,14 @@ def main():
         share = (1.0 / world) if shard_queries else 1.0      # a rank's share of the cells of a launch
         kbytes = {"expand": B * plan.num_record_cells * 32 * share}
         if hash_mode == 1:
-            kbytes["merkle_chains"] = B * plan.num_chain_cells * 32 * share
-        names = {"expand": "expand_fast<%d, true>" % args.lookup_bits if args.lookup_bits in (21, 13, 8) else "expand_kernel_t", "merkle_chains": "k_merkle_bn_quad",
-                 "prologue": "k_prologue_coop", "glue_strands": "k_strands", "glue_and_merkle_strands": "k_strands + k_merkle_gl_coop"}
+            kbytes["chain_emit"] = B * plan.num_chain_cells * 32 * share
+        names = {"expand": "expand_fast<%d, true>" % args.lookup_bits if args.lookup_bits in (21, 13, 8) else "expand_kernel_t", "chain_emit": "k_merkle_bn_emit", "chain_values": "k_merkle_bn_values",
+                 "prologue_values": "k_prologue_values", "perm_records": "k_glp_emit", "glue_strands": "k_strands", "glue_and_merkle_strands": "k_strands + k_merkle_gl_values"}
         kernels = {}
         dom, achieved = "expand", None
         if isol:
-            for i, kk in enumerate(keys[:4]):
-                if kk == "merkle_chains" and hash_mode == 0:
+            for i, kk in enumerate(keys[:NK - 1]):
+                if kk in ("chain_values", "chain_emit") and hash_mode == 0:
                     continue
                 ent = {"kernel": names.get(kk, kk), "ms_isolated": isol[i], "ms_timed_region": overl[i]}
                 if kk in kbytes:

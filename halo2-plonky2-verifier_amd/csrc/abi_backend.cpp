@@ -89,6 +89,8 @@ struct AbiBackend {
     Gl lane_bcast(const Gl &v, int) { return v; }
     void coop_decompose_hashes(uint64_t, int, Gl *) {}
     bool merkle_split(int, int) { return false; }
+    bool merkle_level_skip(HashW<AbiBackend> &) { return false; }
+    bool merkle_tail_skip() { return false; }
     void merkle_begin(int, int) {}
     void merkle_end(int, int) {}
     void query_begin(int) {}

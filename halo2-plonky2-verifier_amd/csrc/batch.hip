@@ -155,7 +155,8 @@ template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(c
     const int sq = q == 0 ? 0 : 1;
     sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
-    sink.ustate = A.unit_state + ((uint64_t)p * A.st.total_unit + strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind]) * 4;
+    const uint64_t unit0 = (uint64_t)p * A.st.total_unit + strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind];
+    sink.ustate = A.unit_state + unit0 * 4; sink.sbx = A.unit_sbox + unit0 * (BN_PARTIAL_ROUNDS * 3);
     ValCfg mc = make_cfg(A, p); mc.split_bn = true;
     QuadB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
     Verifier<QuadB> V(be, A.shape, A.consts);
@@ -180,17 +181,36 @@ __global__ __launch_bounds__(QUAD_BLOCK) void k_merkle_bn_values(BatchArgs A) {
     Sink sink;
     quad_strand<QuadB>(A, sink, p, q, kind);
 }
-// emission: four lanes per work item = (owned unit, strand kind, permutation unit of that strand)
+// one pass (H2W_OPT_CHAIN_PASSES 1): four lanes per (owned unit, kind) walk the path and emit every unit of it - the least arithmetic per
+// cell (352 wavefront-level products per permutation, none twice), serial in the path's depth; blockIdx.y = kind slot
+template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void k_merkle_bn_fused(BatchArgs A) {
+    typedef QuadSinkT<COLS, QUAD_FUSED> Sink; typedef ValBackend<Sink> QuadB;
+    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);
+    const unsigned total = A.sh.n_own_units;
+    if (((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;
+    unsigned idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
+    if (idx >= total) idx = total - 1;
+    int p, q; own_unit_at(A, idx, p, q);
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    Sink sink;
+    quad_strand<QuadB>(A, sink, p, q, kind);
+}
+// emission: four lanes per work item = (strand kind, permutation unit of that strand; owned unit).  The quads of a wavefront share
+// the (kind, unit) and differ in the (proof, query): they reach their unit's permutation together (a wavefront whose quads emitted
+// at different levels would run every one of those emissions with four lanes active).
 template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void k_merkle_bn_emit(BatchArgs A) {
     typedef QuadSinkT<COLS, QUAD_EMIT> Sink; typedef ValBackend<Sink> QuadB;
     stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);
-    const unsigned per_q = A.st.mk_item0[MK_KINDS];
-    const unsigned long long total = (unsigned long long)A.sh.n_own_units * per_q;
-    if ((((unsigned long long)blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;
-    unsigned long long g = ((unsigned long long)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
-    if (g >= total) g = total - 1;                      // tail quads redo the last item (identical bytes)
-    int p, q; own_unit_at(A, (unsigned)(g / per_q), p, q);
-    const unsigned item = (unsigned)(g % per_q);
+    const unsigned per_q = A.st.mk_item0[MK_KINDS], upad = (A.sh.n_own_units + 15u) & ~15u;      // 16 quads = one wavefront per 16 units of an item
+    const unsigned long long total = (unsigned long long)per_q * upad;
+    const unsigned long long g = ((unsigned long long)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
+    if (g >= total) return;                                       // (whole wavefronts: total is a multiple of 16)
+    // items outermost: the wavefronts in flight at one time work on the same few levels of every path of the launch (grouping all levels of a
+    // few hundred units instead - a compact part of the advice - was slower: 6.65 against 5.74 ms, profiles/r03_emit_store_bound.txt)
+    const unsigned item = (unsigned)(g / upad); unsigned ui = (unsigned)(g % upad);
+    if (ui >= A.sh.n_own_units) ui = A.sh.n_own_units - 1;      // tail quads of an item redo its last unit (identical bytes)
+    int p, q; own_unit_at(A, ui, p, q);
     int kind = 0;
 #pragma unroll 1
     for (int k = 1; k < MK_KINDS; k++) if (item >= A.st.mk_item0[k]) kind = k;      // (kinds a shape does not have own no items)
@@ -234,6 +254,7 @@ struct h2w_plan {
     // strands) start / done, 8 / 3 expansion start / done, 4 / 10 / 5 chain kernels start / values done / end, 6 end of call
     hipEvent_t evr[EV_RING][N_EV];
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
+    int chain_passes = 0;            // H2W_OPT_CHAIN_PASSES (0: by the size of the launch)
     int serial_expand = 1;           // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's
     bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
@@ -369,13 +390,14 @@ uint64_t h2w_plan_num_chain_cells(const h2w_plan *p) {      // cells of the Merk
     for (int k = 0; k < MK_KINDS; k++) n += p->st.mk_ncell[0][k] + (uint64_t)(p->shape.num_queries - 1) * p->st.mk_ncell[1][k];
     return n;
 }
-struct WsLayout { size_t recs, cbs, status, units, glp, ctr, total; };
+struct WsLayout { size_t recs, cbs, status, units, sbox, glp, ctr, total; };
 static WsLayout ws_layout(const h2w_plan *p, uint64_t n) {
     WsLayout w; size_t o = 0;
     w.recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
     w.cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
     w.status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
     w.units = o; o += align_up((size_t)n * p->st.total_unit * 4 * sizeof(fr_t), 256);                  // PoseidonBN254 unit states (values phase -> emission)
+    w.sbox = o; o += align_up((size_t)n * p->st.total_unit * BN_PARTIAL_ROUNDS * 3 * sizeof(fr_t), 256);   // ... and the S-box values of their partial rounds
     w.glp = o; o += align_up((size_t)n * p->st.total_glp * GLP_LIST_WORDS * sizeof(uint64_t), 256);     // listed Goldilocks-Poseidon permutations
     w.ctr = o; o += align_up((size_t)n * sizeof(uint32_t), 256);                                       // expansion kernel's per-proof tile counters
     w.total = o;
@@ -486,7 +508,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
     A.recs = (rec_t *)(ws + wl.recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
     A.cbs = (DevCB *)(ws + wl.cbs); A.status = (uint32_t *)(ws + wl.status);
-    A.unit_state = (fr_t *)(ws + wl.units); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
+    A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
     A.bn_tab = p->d_bn_tab;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
@@ -512,22 +534,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
         // 1. prologue strands, values: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks
         if (cm.starts) hipLaunchKernelGGL(k_prologue_values<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_values<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
         H2W_HIP(hipEventRecord(ev[9], stream));
-        // 2. PoseidonBN254 Merkle chains (hash_mode 1): values, then one quad per permutation unit.  They write their cells themselves and no
-        //    block records, so nothing but the challenge blocks orders them against the other kernels of the batch: they run on a side
-        //    stream of the plan and rejoin at the end of the call.
-        if (p->shape.hash_mode == 1) {
-            if (cstream != stream) { H2W_HIP(hipStreamWaitEvent(cstream, ev[9], 0)); forked = true; }
-            H2W_HIP(hipEventRecord(ev[4], cstream));
-            if (nunits) hipLaunchKernelGGL(k_merkle_bn_values, dim3((nunits * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, nkinds), dim3(QUAD_BLOCK), 0, cstream, A);
-            H2W_HIP(hipEventRecord(ev[10], cstream));
-            const unsigned long long items = (unsigned long long)nunits * p->st.mk_item0[MK_KINDS];
-            if (items) {
-                const dim3 egrid((unsigned)((items * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK));
-                if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_emit<true>, egrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_emit<false>, egrid, dim3(QUAD_BLOCK), 0, cstream, A);
-            }
-            H2W_HIP(hipEventRecord(ev[5], cstream));
-        }
-        // 3. the records of the listed Goldilocks-Poseidon permutations: with PoseidonBN254 caps the prologues' (now); with Goldilocks caps
+        // 2. the records of the listed Goldilocks-Poseidon permutations: with PoseidonBN254 caps the prologues' (now); with Goldilocks caps
         //    together with the Merkle strands' (below)
         const unsigned n_pro_perms = A.sh.n_own_proofs * p->st.pro_nglp, n_mk_perms = nunits * p->st.q_nglp;
         auto glp_emit = [&](unsigned n) -> int {
@@ -538,6 +545,25 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
         };
         if (p->shape.hash_mode == 1) { if (glp_emit(n_pro_perms) != 0) return -1; }
         H2W_HIP(hipEventRecord(ev[1], stream));
+        // 3. PoseidonBN254 Merkle chains (hash_mode 1): values, then one quad per permutation unit.  They write their cells themselves and no
+        //    block records, so nothing but the challenge blocks orders them against the other kernels of the batch: they run on a side
+        //    stream of the plan and rejoin at the end of the call.
+        if (p->shape.hash_mode == 1) {
+            if (cstream != stream) { H2W_HIP(hipStreamWaitEvent(cstream, ev[9], 0)); forked = true; }
+            H2W_HIP(hipEventRecord(ev[4], cstream));
+            const dim3 sgrid((nunits * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, nkinds);
+            // one pass or two (include/h2w.h H2W_OPT_CHAIN_PASSES): a launch whose paths do not fill the chip is bound by the depth of a path - split it
+            const int passes = p->chain_passes ? p->chain_passes : (nunits <= 512 ? 2 : 1);
+            if (nunits && passes == 1) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_fused<true>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_fused<false>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
+            if (nunits && passes != 1) hipLaunchKernelGGL(k_merkle_bn_values, sgrid, dim3(QUAD_BLOCK), 0, cstream, A);
+            H2W_HIP(hipEventRecord(ev[10], cstream));
+            const unsigned long long items = passes == 1 ? 0ull : (unsigned long long)((nunits + 15u) & ~15u) * p->st.mk_item0[MK_KINDS];
+            if (items) {
+                const dim3 egrid((unsigned)((items * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK));
+                if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_emit<true>, egrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_emit<false>, egrid, dim3(QUAD_BLOCK), 0, cstream, A);
+            }
+            H2W_HIP(hipEventRecord(ev[5], cstream));
+        }
         // 4. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per owned (proof, query);
         //    Goldilocks-Poseidon Merkle strands (hash_mode 0), values: one cooperating wavefront per (proof, query, tree)
         H2W_HIP(hipEventRecord(ev[7], stream));
@@ -901,6 +927,7 @@ int h2w_plan_configure(h2w_plan *p, int option, int value) {
     if (!p) { set_error("h2w_plan_configure: null plan"); return -1; }
     if (option == H2W_OPT_FORK_CHAINS) { p->fork_chains = value != 0; return 0; }
     if (option == H2W_OPT_SERIAL_EXPAND) { p->serial_expand = value != 0; return 0; }      // (negative: the default, on)
+    if (option == H2W_OPT_CHAIN_PASSES) { if (value < 0 || value > 2) { set_error("h2w_plan_configure: H2W_OPT_CHAIN_PASSES is 0 (by launch size), 1 or 2"); return -1; } p->chain_passes = value; return 0; }
     set_error("h2w_plan_configure: unknown option"); return -1;
 }
 

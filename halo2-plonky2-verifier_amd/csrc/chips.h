@@ -380,11 +380,13 @@ template <class B> struct MerkleTreeChip {
         H node = hs.hash_or_noop(leaf, n_leaf);
         int n = n_sib < n_bits ? n_sib : n_bits;
         for (int i = 0; i < n; i++) {
+            if (be.merkle_level_skip(node)) continue;      // (device emission windows: the level is another quad's; no-op elsewhere)
             H sib = sibling(i);
             H left = hs.select(sib, node, bits[i]);
             H right = hs.select(node, sib, bits[i]);
             node = hs.two_to_one(left, right);
         }
+        if (be.merkle_tail_skip()) return;             // (device emission windows: the cap lookup is the last unit's quad's)
         H root = hs.select_from_idx(n_cap, cap, cap_index);
         hs.assert_equal(root, node);                 // no cells
     }

@@ -16,6 +16,7 @@
 // Together they emit exactly the records the sequential template code (chips.h PoseidonPermutationChip) emits, at the same
 // indices — tests/test_gpu_batch.py compares the resulting advice with the oracle byte for byte.
 #pragma once
+#include <type_traits>
 #include "valbackend.h"
 
 namespace h2w {
@@ -412,20 +413,21 @@ constexpr BnSrc bn_map_partial(int c) {
     return (i == 0 || i == 2) ? bA(4 + k - 1) : i == 1 ? bV(k) : i == 3 ? bV(7) : bV(12 + k - 1);
 }
 
-enum { QUAD_VALUES = 1, QUAD_EMIT = 2 };
+enum { QUAD_VALUES = 1, QUAD_EMIT = 2, QUAD_FUSED = 3 };      // QUAD_FUSED: one quad walks its strand AND emits every unit of it (one pass, serial in the path's depth)
 template <bool COLS, int MODE> struct QuadSinkT {
     static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = true; static constexpr int kHashMode = 1;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4; ColPolicy<COLS> cc;
     fr_t *ustate;                  // output states of this strand's permutation units, [unit][4] (written by QUAD_VALUES, read by QUAD_EMIT)
+    fr_t *sbx;                     // the S-box chains of their partial rounds, [unit][BN_PARTIAL_ROUNDS][3] = canonical x^2, x^4, x^5 (QUAD_VALUES -> QUAD_EMIT)
     int unit_local = 0;            // units of the strand passed so far
     int my_w = 0, last_w = 0;      // QUAD_EMIT: the unit this quad emits; the strand's last unit (its window also holds the cells behind it)
     bool act = true;               // QUAD_EMIT: the cursor is inside this quad's window
     __device__ __forceinline__ void set_window(int w, int n_units) { my_w = w; last_w = n_units > 0 ? n_units - 1 : 0; unit_local = 0; act = w == 0; }
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-        if (MODE == QUAD_EMIT && l4 == 0 && act) g_store_rec(recs + nrec, a, b, c, d);
+        if (MODE != QUAD_VALUES && l4 == 0 && act) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
-    __device__ __forceinline__ void cell(const fr_t &v) { if (MODE == QUAD_EMIT && l4 == 0 && act) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (MODE != QUAD_VALUES && l4 == 0 && act) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
     __device__ int coop_lanes() { return 1; }
@@ -510,6 +512,42 @@ template <bool COLS, int MODE> struct QuadSinkT {
             if (2 * k + 1 < N || !hiq) { H2W_GSTORE64(g, t[k - K0].x); H2W_GSTORE64(g + 1, t[k - K0].y); }
         }
     }
+    // The partial-round layer as a WAVEFRONT-wide stream: the quad-wise flush above writes 64 contiguous bytes per quad and store instruction,
+    // i.e. sixteen 64-byte segments in sixteen different permutations per wavefront instruction - with every level of every path in flight that is
+    // ~32 k interleaved write streams and the kernel sat at 3.7 TB/s with its arithmetic at 45 % (profiles/r03_emit_store_bound.txt).  Here the 64 lanes
+    // write 1 KB of ONE quad's layer per instruction (the form that streams at the ceiling, tools/ubench_store*.hip), quad after quad: lane j owns the
+    // 16-byte pieces j and 64 + j of every quad's 104-piece layer; where a piece comes from (value slot of that quad | table entry) is a per-lane
+    // constant, worked out once per permutation.
+    typedef __attribute__((address_space(3))) const sq16_t lds_sq16;
+    struct Wide { int off0, off1, kind0, kind1; bool has1; int lane; unsigned long long gq; };      // gq: this lane's quad's layer base (the same on the quad's four lanes)
+    static __device__ __forceinline__ void wide_desc(int pc, int &off, int &kind) {
+        const int c = pc >> 1; const BnSrc sd = bn_map_partial(c < 52 ? c : 51);
+        kind = sd.kind; off = (sd.kind == 0 ? sd.idx * BN_SLOT_SQ : sd.idx * 2) + (pc & 1);
+    }
+    static __device__ __forceinline__ Wide wide_init(const Em &e) {
+        Wide w; w.lane = threadIdx.x & 63; w.has1 = w.lane < 2 * 52 - 64;
+        wide_desc(w.lane, w.off0, w.kind0); wide_desc(w.has1 ? 64 + w.lane : 0, w.off1, w.kind1);
+        w.gq = e.gdst - (unsigned long long)e.l * 16;
+        return w;
+    }
+    // quads [Q0, Q1) of the wavefront: the LDS reads ...
+    template <int Q0, int Q1> static __device__ __forceinline__ void wide_load(const Wide &w, lds_sq16 *valw, lds_sq16 *tab, lds_sq16 *baseA, lds_sq16 *baseB, sq16_t *t0, sq16_t *t1) {
+        lds_sq16 *b0 = (w.kind0 == 0 ? valw : w.kind0 == 1 ? tab : w.kind0 == 2 ? baseA : baseB) + w.off0;
+        lds_sq16 *b1 = (w.kind1 == 0 ? valw : w.kind1 == 1 ? tab : w.kind1 == 2 ? baseA : baseB) + w.off1;
+        const int q0 = w.kind0 == 0 ? 2 : 0, q1 = w.kind1 == 0 ? 2 : 0;      // a value slot holds the sixteen quads' values 32 bytes apart
+#pragma unroll
+        for (int q = Q0; q < Q1; q++) { t0[q - Q0].x = b0[q * q0].x; t0[q - Q0].y = b0[q * q0].y; t1[q - Q0].x = b1[q * q1].x; t1[q - Q0].y = b1[q * q1].y; }
+    }
+    // ... and their stores: 1 KB + 640 B contiguous per quad
+    template <int Q0, int Q1> static __device__ __forceinline__ void wide_store(const Wide &w, const sq16_t *t0, const sq16_t *t1) {
+#pragma unroll
+        for (int q = Q0; q < Q1; q++) {
+            const unsigned long long gb = readlane64(w.gq, 4 * q) + (unsigned long long)w.lane * 16;
+            unsigned long long *g = reinterpret_cast<unsigned long long *>(gb);
+            H2W_GSTORE64(g, t0[q - Q0].x); H2W_GSTORE64(g + 1, t0[q - Q0].y);
+            if (w.has1) { H2W_GSTORE64(g + 128, t1[q - Q0].x); H2W_GSTORE64(g + 129, t1[q - Q0].y); }
+        }
+    }
     // column-major layout, a layer that crosses into the next column (rare): per-cell addresses
     template <int N, class MapFn> __device__ __noinline__ void flush_layer_cols(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
         if constexpr (COLS) {
@@ -533,12 +571,30 @@ template <bool COLS, int MODE> struct QuadSinkT {
         const BnSrc s = map(c);
         return s.kind == 0 ? e.val + s.idx * BN_SLOT_SQ + (e.l & 1) : s.kind == 1 ? e.tabh + s.idx * 2 : s.kind == 2 ? baseA + s.idx * 2 : baseB + s.idx * 2;
     }
+    // A whole Merkle level (two selects, the four state constants, one permutation unit: merkle/mod.rs:66-74) that is not this quad's:
+    // step over it - its cells belong to the quad of that unit - and, if this quad's unit is the next one, pick up the node it starts from.
+    __device__ __forceinline__ bool level_skip(fr_t &node, bool &zc_ref) {
+        if constexpr (MODE != QUAD_EMIT) return false;
+        else {
+            const int k = unit_local;
+            if (k == my_w) return false;
+            if (k + 1 == my_w) node = g_load_fr(ustate + (uint64_t)k * 4);
+            if (!zc_ref) { cell_off += 1; zc_ref = true; }
+            cell_off += 2 * 8 + 4 + BN_PERM_CELLS;
+            unit_local = k + 1;
+            const int cur = unit_local < last_w ? unit_local : last_w;
+            act = cur == my_w;
+            return true;
+        }
+    }
+    __device__ __forceinline__ bool tail_skip() const { return MODE == QUAD_VALUES || (MODE == QUAD_EMIT && !act); }      // the cap lookup: cells only (no value anyone uses)
     // One permutation unit of the strand (PoseidonBN254PermutationChip::permute, hash/poseidon_bn254/permutation.rs:190-203).
     __device__ __forceinline__ bool bn_emit_inline(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
         if constexpr (MODE == QUAD_VALUES) { bn_values(st, cfg); unit_local++; return true; }
+        else if constexpr (MODE == QUAD_FUSED) { bn_emit_cells<false>(st, cfg, zc_ref); return true; }
         else {
             const int k = unit_local++;
-            if (k == my_w) bn_emit_cells(st, cfg, zc_ref);
+            if (k == my_w) bn_emit_cells<true>(st, cfg, zc_ref);
             else {
                 if (k + 1 == my_w) {              // the state this quad's unit starts from: the output of the unit before it
                     const fr_t *u = ustate + (uint64_t)k * 4;
@@ -555,9 +611,12 @@ template <bool COLS, int MODE> struct QuadSinkT {
     }
     // values phase: Montgomery-form state, lane l owns element l.  x^5 = three products; a partial round = four wavefront-level
     // products (lanes 1-3 form their terms of the sparse row beside lane 0's first S-box product; the column update and S_0 s0' share
-    // the last one); a full round = 3 + 4.  The output state (canonical) goes to the strand's unit buffer.
+    // the last one); a full round = 3 + 4.  The output state (canonical) goes to the strand's unit buffer, the partial rounds' S-box
+    // values to its S-box buffer.
     __device__ __noinline__ void bn_values(fr_t *st, const ValCfg &cfg) {
         const int l = l4, lm = l > 0 ? l - 1 : 0; const uint64_t ninv = cfg.P.ninv;
+        const fr_t one = fr_from_u64(1); fr_t X5p = fr_zero();
+        fr_t *const sbu = sbx + (uint64_t)unit_local * (BN_PARTIAL_ROUNDS * 3);
         fr_t S = fr_mont_mul(fr_sel(l < 2, fr_sel(l == 0, st[0], st[1]), fr_sel(l == 2, st[2], st[3])), cfg.P.r2, ninv);
         auto sbox = [&]() { const fr_t X2 = fr_mont_mul(S, S, ninv), X4 = fr_mont_mul(X2, X2, ninv); S = fr_mont_mul(X4, S, ninv); };
         auto mix = [&](int mb) {
@@ -573,18 +632,32 @@ template <bool COLS, int MODE> struct QuadSinkT {
             if (half == 1) {
 #pragma unroll 1
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                    // Four wavefront-level products per round; the lanes that idle beside lane 0's S-box chain turn that chain's values into
+                    // the canonical x^2, x^4, x^5 the emission shows in its cells (X / R = mont(X, 1)), so that the emission does not walk the chain again:
+                    //   A: lane 0  X2 = s0 s0         | lanes j  S_j s_j
+                    //   B: lane 0  X4 = X2 X2         | lane 1   x^2 = X2 / R       | lane 2   x^5 of the previous round = X5' / R
+                    //   C: lane 0  X5 = X4 s0 ; + c   | lane 1   x^4 = X4 / R
+                    //   E: lane 0  S_0 s0'            | lanes k  S'_k s0'
                     const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                    fr_t *const sb = sbu + (uint64_t)r * 3;
                     const fr_t ksxm = bnk(1, ix + l);
-                    const fr_t A_ = fr_mont_mul(S, fr_sel(l == 0, S, ksxm), ninv);        // lane 0: s0^2 | lanes j: S_j s_j
-                    const fr_t X4 = fr_mont_mul(A_, A_, ninv);
-                    const fr_t s0n = fr_add(fr_mont_mul(X4, S, ninv), bnk(1, ic));         // lane 0: s0' = s0^5 + c
-                    const fr_t s0 = quad_bcast<0>(s0n);
-                    const fr_t E_ = fr_mont_mul(s0, fr_sel(l == 0, ksxm, bnk(1, ix + BN_WIDTH + lm)), ninv);      // lane 0: S_0 s0' | lanes k: S'_k s0'
+                    const fr_t A_ = fr_mont_mul(S, fr_sel(l == 0, S, ksxm), ninv);
+                    const fr_t X2b = quad_bcast<0>(A_);
+                    const fr_t B_ = fr_mont_mul(fr_sel(l == 2, X5p, X2b), fr_sel(l == 0, X2b, one), ninv);
+                    if (l == 1) g_store_fr(sb, B_);
+                    if (l == 2 && r > 0) g_store_fr(sb - 1, B_);
+                    const fr_t X4b = quad_bcast<0>(B_);
+                    const fr_t C_ = fr_mont_mul(X4b, fr_sel(l == 0, S, one), ninv);
+                    if (l == 1) g_store_fr(sb + 1, C_);
+                    X5p = quad_bcast<0>(C_);
+                    const fr_t s0 = fr_add(X5p, bnk(1, ic));                                                    // s0' = s0^5 + c (the same on every lane)
+                    const fr_t E_ = fr_mont_mul(s0, fr_sel(l == 0, ksxm, bnk(1, ix + BN_WIDTH + lm)), ninv);
                     fr_t incl = fr_sel(l == 0, E_, A_);
                     { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
                     { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
                     S = fr_sel(l > 0, fr_add(E_, S), quad_bcast<3>(incl));
                 }
+                { const fr_t x5c = fr_mont_mul(X5p, one, ninv); if (l == 2) g_store_fr(sbu + (uint64_t)(BN_PARTIAL_ROUNDS - 1) * 3 + 2, x5c); }      // the last round's x^5
             }
 #pragma unroll 1
             for (int r = 0; r < BN_FULL_ROUNDS / 2; r++) {
@@ -594,12 +667,14 @@ template <bool COLS, int MODE> struct QuadSinkT {
                 mix(half == 0 && last ? BK_P : BK_M);
             }
         }
-        const fr_t s = fr_mont_mul(S, fr_from_u64(1), ninv);                               // back to canonical
+        const fr_t s = fr_mont_mul(S, one, ninv);                                          // back to canonical
         g_store_fr(ustate + (uint64_t)unit_local * 4 + l, s);
         st[0] = quad_bcast<0>(s); st[1] = quad_bcast<1>(s); st[2] = quad_bcast<2>(s); st[3] = quad_bcast<3>(s);
     }
     // PoseidonBN254 permutation with its 4,032 cells emitted by the quad itself.
-    __device__ __noinline__ void bn_emit_cells(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
+    // PRE: the partial rounds' S-box values come from the values phase (sbx): two wavefront-level products per partial round, none of them
+    // dependent on another of the same round; !PRE (the one-pass kernel): the emitter walks the S-box chain itself, five products.
+    template <bool PRE> __device__ __noinline__ void bn_emit_cells(fr_t *st, const ValCfg &cfg, bool &zc_ref) {
         bool zc = zc_ref;                      // by value: a reference would be re-read with a flat load (vmcnt(0)) at every mix
         const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
         Em e; e.l = l;
@@ -641,6 +716,58 @@ template <bool COLS, int MODE> struct QuadSinkT {
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             if (half == 1) {
+                if constexpr (PRE) {
+                    // The S-box values come in one value per lane (lane 0: x^2, 1: x^4, 2 and 3: x^5), two rounds per request, requested two rounds
+                    // (~110 vector-memory instructions) before they are used.  Loads and stores retire in order on one counter of at most 63 in
+                    // flight: a load is back once the cell stores issued before it have drained, and by then it is.  Requested one round ahead
+                    // through loop-carried registers the compiler's wait was vmcnt(6) every round, i.e. a drain of the wavefront's whole store queue
+                    // (profiles/r03_pmc_emit.txt: 64 % of the wavefront cycles parked in s_waitcnt).
+                    const fr_t *sb = sbx + (uint64_t)my_w * (BN_PARTIAL_ROUNDS * 3) + (l < 3 ? l : 2);
+                    Wide wd = wide_init(e);
+                    lds_sq16 *const valw = (lds_sq16 *)s_bn_val + (threadIdx.x >> 6) * BN_NSLOT * BN_SLOT_SQ;
+                    auto round = [&](int r, const fr_t &qv, auto pend_tag) {
+                        //   P: lane 0  S_0 * s0'  | lanes j  S_j * s_j        (the sparse row)           s0' = x^5 + c: known from the values phase
+                        //   Q:                    | lanes k  S'_k * s0'       (the column update)
+                        const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, lm = l > 0 ? l - 1 : 0, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                        constexpr bool pend = !COLS && decltype(pend_tag)::value;      // the previous round's layer is still staged: it leaves between the products
+                        lds_sq16 *const tab = (lds_sq16 *)s_bn_tab, *const wA = tab + (ix - (BN_WIDTH * 2 - 1)) * 2, *const wB = tab + (ic - 1) * 2;
+                        sq16_t t0[6], t1[6], u0[5], u1[5], v0[5], v1[5];
+                        const fr_t x2 = quad_bcast<0>(qv), x4 = quad_bcast<1>(qv), x5 = quad_bcast<2>(qv);
+                        const fr_t s0n = fr_add(x5, bnk(0, ic));
+                        const fr_t ksxm = bnk(1, ix + l);
+                        if (pend) wide_load<0, 6>(wd, valw, tab, wA, wB, t0, t1);
+                        const fr_t P_ = fr_mont_mul(fr_sel(l == 0, s0n, s), ksxm, ninv);
+                        if (pend) { wide_store<0, 6>(wd, t0, t1); wide_load<6, 11>(wd, valw, tab, wA, wB, u0, u1); }
+                        const fr_t Q_ = fr_mont_mul(s0n, bnk(1, ix + BN_WIDTH + lm), ninv);
+                        if (pend) { wide_store<6, 11>(wd, u0, u1); wide_load<11, 16>(wd, valw, tab, wA, wB, v0, v1); }
+                        fr_t incl = P_;                                      // S[j] * s_j, then the running sums over the quad
+                        { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
+                        { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
+                        const fr_t nv = fr_add(Q_, s);
+                        if (pend) { wide_store<11, 16>(wd, v0, v1); e.cell0 += 52; e.gdst += 52ull * 32; wd.gq += 52ull * 32; }
+                        put(e, l, s);                                        // slots 0-3: the state before the round
+                        put_if(e, l == 0, 4, x2); put_if(e, l == 0, 5, x4); put_if(e, l == 0, 6, x5); put_if(e, l == 0, 7, s0n);
+                        put(e, 8 + l, incl);
+                        put_if(e, l > 0, 12 + lm, nv);
+                        const fr_t ns0 = quad_bcast<3>(incl);
+                        s = fr_sel(l > 0, nv, ns0);
+                        if (COLS || r == BN_PARTIAL_ROUNDS - 1) flush_layer<52>(e, bn_map_partial, e.tabh + ix * 2, e.tabh + ic * 2);
+                    };
+                    // round 0 (nothing staged before it), rounds 1 .. 54 in pairs (no branch inside: a join makes the compiler's wait conservative),
+                    // round 55
+                    static_assert(BN_PARTIAL_ROUNDS % 2 == 0, "rounds are walked in pairs");
+                    fr_t qc0 = g_load_fr(sb + 3), qc1 = g_load_fr(sb + 6);
+                    { const fr_t q = g_load_fr(sb); round(0, q, std::false_type()); }
+                    asm volatile("" :: "v"(qc0.l[0]), "v"(qc0.l[2]), "v"(qc1.l[0]), "v"(qc1.l[2]));      // (both are back by now: nothing is pending at the head of the loop)
+#pragma unroll 1
+                    for (int r = 1; r < BN_PARTIAL_ROUNDS - 1; r += 2) {
+                        const int rn = r + 2 < BN_PARTIAL_ROUNDS - 1 ? r + 2 : r;
+                        const fr_t qn0 = g_load_fr(sb + 3 * rn), qn1 = g_load_fr(sb + 3 * (rn + 1));
+                        round(r, qc0, std::true_type()); round(r + 1, qc1, std::true_type());
+                        qc0 = qn0; qc1 = qn1;
+                    }
+                    { const fr_t q = g_load_fr(sb + 3 * (BN_PARTIAL_ROUNDS - 1)); round(BN_PARTIAL_ROUNDS - 1, q, std::true_type()); }
+                } else
 #pragma unroll 1
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
                     // Five wavefront-level Montgomery products per partial round: the lanes that have no S-box do their own work

@@ -225,6 +225,8 @@ template <class Sink> struct ValBackend {
         sink.skip(cfg.st->mk_nrec[s][kind], cfg.st->mk_ncell[s][kind]);
         return true;
     }
+    HF bool merkle_level_skip(HashW<ValBackend> &node) { if constexpr (kBnUnits) return sink.level_skip(node.f, zero_cached); else return false; }
+    HF bool merkle_tail_skip() { if constexpr (kBnUnits) return sink.tail_skip(); else return false; }
     HF void merkle_begin(int q, int kind) { sink.merkle_begin(q, kind, zero_cached, unit_idx); }
     HF void merkle_end(int q, int kind) { sink.merkle_end(q, kind, zero_cached); }
     HF void query_begin(int q) { sink.query_begin(q, unit_idx); }

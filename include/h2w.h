@@ -302,6 +302,14 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
  * waits for the expansion kernel of the plan's previous batch call, whatever stream that was issued on, so that the latency-bound
  * strands of the other calls in flight find free CUs; the cells written are the same either way. */
 #define H2W_OPT_SERIAL_EXPAND 2
+/* H2W_OPT_CHAIN_PASSES (PoseidonBN254 caps): how the Merkle paths (merkle/mod.rs:57-78) are generated.
+ * 1: one quad per path walks it and emits as it goes - the least arithmetic per cell, serial in the path's depth (18 permutations at 2^20
+ *    rows, ~7 ms): right when many paths are in flight (large batches, several launches pipelined), which hide that latency.
+ * 2: a values pass walks every path serially, then one quad per permutation emits its cells - all levels of all paths side by side.  The
+ *    emission is a streaming kernel whose time is proportional to the work (1 / world of it in a sharded launch), at the price of evaluating
+ *    every permutation twice: right for small or sharded launches, which the depth of a path would otherwise bound.
+ * 0 (default): 2 for launches of at most 512 (proof, query) units of this rank, else 1.  The cells are the same either way. */
+#define H2W_OPT_CHAIN_PASSES 3
 int h2w_plan_configure(h2w_plan *, int option, int value);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the streams it launches on:
  * ms[0] = prologue strands (values; with PoseidonBN254 caps also the records of their permutations), ms[1] = query glue strands (with

@@ -45,7 +45,7 @@ def _count(lines, a, b, pat):
 
 def test_chain_round_loops_have_no_scratch_or_flat_accesses(tmp_path):
     lines = _asm("batch.hip", tmp_path)
-    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0EE14bn_emit_inline")       # the flat-layout emitter of k_merkle_bn_quad
+    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi2EE13bn_emit_cells")       # the flat-layout emitter of k_merkle_bn_emit
     loops = list(_loops(lines, lo, hi))
     partial = [(a, b) for a, b in loops if 780 <= _count(lines, a, b, "v_mad_u64_u32") <= 830]
     assert partial, "partial-round loop (five products, 805 multiply-adds) not found"

@@ -8,12 +8,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False, valid=False, cap_height=4):
+def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False, valid=False, cap_height=4, passes=0):
     import torch
     ko, kh = consts
     sh = h2w.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc, cap_height=cap_height)
     osh = oracle.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc, cap_height=cap_height)
     plan = h2w_api.Plan(sh, kh)
+    if passes:
+        plan.configure(3, passes)          # H2W_OPT_CHAIN_PASSES
     n = len(seeds)
     proofs = [oracle.prove_fri(osh, ko, s) if valid else oracle.synth_proof(osh, s) for s in seeds]   # valid: oracle/prover.inc
     host = torch.empty(n * plan.proof_words, dtype=torch.int64)
@@ -51,6 +53,15 @@ def test_small_shapes_every_cell(h2w, h2w_api, oracle, consts, mode):
     run_batch(h2w, h2w_api, oracle, consts, (6, 2, 1, mode), [1, 2, 3])          # no fold step, 2 queries
     run_batch(h2w, h2w_api, oracle, consts, (7, 3, 2, mode), [4])                # one fold step (the path no reference test exercises)
     run_batch(h2w, h2w_api, oracle, consts, (5, 1, 1, mode), [5, 6], wlrc=0)     # single query; SVG-era loader
+
+
+@pytest.mark.parametrize("passes", [1, 2])
+def test_merkle_paths_in_one_pass_and_in_two(h2w, h2w_api, oracle, consts, passes):
+    """H2W_OPT_CHAIN_PASSES: the PoseidonBN254 Merkle paths as one kernel that walks and emits (1) or as a values pass plus one quad per
+    permutation (2: every level of every path side by side).  Same cells; the default picks by the size of the launch."""
+    run_batch(h2w, h2w_api, oracle, consts, (8, 3, 2, 1), [61, 62, 63], passes=passes)          # one fold step, rate_bits 2
+    run_batch(h2w, h2w_api, oracle, consts, (10, 4, 1, 1), [0xF1B00001], passes=passes)         # BASELINE configs[0]
+    run_batch(h2w, h2w_api, oracle, consts, (4, 2, 1, 1), [64], passes=passes, cap_height=4)    # lde_bits 5: one-level paths, unit-less oracle strands
 
 
 @pytest.mark.parametrize("lookup_bits", [13, 8, 17])
@@ -112,6 +123,8 @@ def run_custom(h2w, h2w_api, oracle, consts, seeds, valid=False, **kw):
     ko, kh = consts
     sh, osh = _custom(h2w, oracle, **kw)
     plan = h2w_api.Plan(sh, kh)
+    if passes:
+        plan.configure(3, passes)          # H2W_OPT_CHAIN_PASSES
     n = len(seeds)
     proofs = [oracle.prove_fri(osh, ko, s) if valid else oracle.synth_proof(osh, s) for s in seeds]   # valid: oracle/prover.inc
     host = torch.empty(n * plan.proof_words, dtype=torch.int64)
