@@ -16,7 +16,7 @@ namespace h2w {
 
 struct AbiBackend {
     typedef h2w_assigned_t Gl; typedef h2w_assigned_t Bool; typedef h2w_assigned_t Fr; typedef h2w_assigned_t Big;
-    static constexpr bool kCoopPoseidon = false, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = -1;
+    static constexpr bool kCoopPoseidon = false, kSplitOnly = false, kBnUnits = false, kDevSponge = false; static constexpr int kHashMode = -1;
     h2w_ctx *ctx; int mode; const uint64_t *proof; std::vector<h2w_assigned_t> wires; uint32_t status = 0; int rc = 0;
     AbiBackend(h2w_ctx *c, int hash_mode, const uint64_t *proof_words, size_t n_words) : ctx(c), mode(hash_mode), proof(proof_words), wires(n_words) {}
     void ck(int r) { if (r != 0 && rc == 0) rc = r; }
@@ -85,9 +85,7 @@ struct AbiBackend {
         else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = proof[w + i]; wires[w] = fr_witness(v); }
     }
     bool coop_load_proof() { return false; }
-    int coop_lanes() { return 1; }
-    Gl lane_bcast(const Gl &v, int) { return v; }
-    void coop_decompose_hashes(uint64_t, int, Gl *) {}
+    void note_cap_hash(uint64_t) {}
     bool merkle_split(int, int) { return false; }
     bool merkle_level_skip(HashW<AbiBackend> &) { return false; }
     bool merkle_tail_skip() { return false; }

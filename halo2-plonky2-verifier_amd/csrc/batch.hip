@@ -21,29 +21,23 @@
 #include <cstdlib>
 #include <cstdio>
 #include "common.h"
-#include "valbackend.h"
-#include "coop.h"
 #include "batchargs.h"
 
 namespace h2w {
 
 
 struct PlanSink {
-    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = -1;
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false, kDevSponge = false; static constexpr int kHashMode = -1;
     void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     std::vector<uint64_t> *meta; const TemplateTable *tt; StrandTable *st;
     uint64_t nrec = 0, cell_off = 0, cur_q_rec = 0, cur_q_cell = 0, mk_rec0 = 0, mk_cell0 = 0; bool mk_zc = false;
     std::vector<uint64_t> *unit_cell = nullptr; uint64_t nunit = 0, cur_q_unit = 0, mk_unit0 = 0; bool pu_zc = false;
     uint64_t nglp = 0, cur_q_glp = 0, mk_glp0 = 0; int cur_q = -1;
-    std::vector<LoadItem> *items = nullptr;
+    std::vector<LoadItem> *items = nullptr, *cap_items = nullptr;
     void note_load(uint64_t w, int kind) { LoadItem it; it.word = (uint32_t)w; it.kind = (uint32_t)kind; it.rec = nrec; it.cell = cell_off; items->push_back(it); }
+    void note_cap_hash(uint64_t w) { if (cap_items) { LoadItem it; it.word = (uint32_t)w; it.kind = 4; it.rec = nrec; it.cell = cell_off; cap_items->push_back(it); } }
     bool coop_load_proof(const ValCfg &) { return false; }
     bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
-    int coop_lanes() { return 1; }
-    int coop_lane() { return 0; }
-    uint64_t lane_bcast(uint64_t v, int) { return v; }
-    void begin_lane_cells(uint64_t, bool) {}
-    void end_lane_cells(uint64_t) {}
     void bn_perm_begin(bool zc) { unit_cell->push_back(cell_off); pu_zc = zc; }
     void bn_perm_end(bool zc) { if (!pu_zc && zc) st->first_zero_unit = (int64_t)nunit; nunit++; }
     void glp_note() { nglp++; }
@@ -84,24 +78,34 @@ struct PlanSink {
 #endif
 #define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(H2W_QUAD_EU, H2W_QUAD_EU)))
 
-template <bool COLS, bool VALPH, int HM> __device__ __forceinline__ void coop_sink_init(CoopSinkT<COLS, VALPH, HM> &sink, const BatchArgs &A, int p, int q) {
-    sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
-    sink.glp = A.glp_list + (uint64_t)p * A.st.total_glp * GLP_LIST_WORDS; sink.small_mds = A.glp_small_mds != 0;
-    sink.bind_lds();
-}
-// one wavefront per proof: wave-uniform gadget code; every rank of a sharded run computes every prologue's VALUES (it needs the
-// challenges); only the proof's owner writes the block (direct cells, records, permutation list)
-template <bool COLS> __global__ __launch_bounds__(64) void k_prologue_values(BatchArgs A) {
-    typedef CoopSinkT<COLS, true> Sink; typedef ValBackend<Sink> CoopB;
-    __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
-    stage_glp_consts(A.consts, threadIdx.x, 64);
-    const int p = blockIdx.x;
-    Sink sink; coop_sink_init(sink, A, p, -1); sink.nrec = 0; sink.cell_off = 0; sink.glp_slot = 0;
-    sink.emit = own_prologue(A, p);
-    CoopB be(sink, make_cfg(A, p), true);
-    Verifier<CoopB> V(be, A.shape, A.consts);
-    V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
-    if (threadIdx.x == 0) A.status[p] = be.status ? be.status : sink.load_flag;
+// WitnessChip::load_proof_with_pis (witness/mod.rs:267-294) and the limb decompositions of the caps' BN254 hashes (challenger/mod.rs:65-74,
+// hash/poseidon_bn254/hash.rs:31-43): every item is a function of a few proof words - one lane per (proof, item).  Every rank checks every
+// proof's words (status 4); the proof's owner writes the records and cells.
+template <bool COLS> __global__ __launch_bounds__(256) void k_prologue_load(BatchArgs A) {
+    const int p = blockIdx.y; const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n_load_items + A.n_cap_items) return;
+    const bool emit = own_prologue(A, p);
+    rec_t *recs = A.recs + (uint64_t)p * A.rec_stride; fr_t *out = block_out(A, p, -1);
+    const uint64_t *ip = reinterpret_cast<const uint64_t *>(A.load_items + i);
+    const uint64_t wk = g_load_u64(ip), irec = g_load_u64(ip + 1), icell = g_load_u64(ip + 2);
+    const uint32_t word = (uint32_t)wk, kind = (uint32_t)(wk >> 32);
+    const uint64_t *w = A.proofs + (uint64_t)p * A.proof_words + word; const uint64_t w0 = g_load_u64(w);
+    bool bad = false;
+    if (kind <= 1) { if (emit) g_store_rec(recs + irec, w0, 0, 0, 0); bad = w0 >= GL_P; }
+    else {
+        const uint64_t w1 = g_load_u64(w + 1), w2 = g_load_u64(w + 2), w3 = g_load_u64(w + 3);
+        if (kind == 2) { if (emit) g_store_rec(recs + irec, w0, w1, w2, w3); bad = w0 >= GL_P || w1 >= GL_P || w2 >= GL_P || w3 >= GL_P; }
+        else {
+            fr_t v; v.l[0] = w0; v.l[1] = w1; v.l[2] = w2; v.l[3] = w3;
+            if (kind == 3) { ColPolicy<COLS> cc; cc.init(A.cm); if (emit) g_store_fr(out + cc.map(icell), v); bad = fr_geq_mod(v); }
+            else if (emit) {      // kind 4: RangeChip::decompose_le(x, 56, 5) - 13 cells of limb sums + 5 range checks
+                DevSinkT<COLS> sink; sink.recs = recs; sink.nrec = irec; sink.out = out; sink.cell_off = icell; sink.ncells = A.ncells; sink.cc.init(A.cm);
+                ValBackend<DevSinkT<COLS>> be(sink, make_cfg(A, p), true);
+                uint64_t limbs[5]; be.decompose_le_56_5(v, limbs);
+            }
+        }
+    }
+    if (bad) atomicOr(&A.load_flag[p], 4u);
 }
 
 // one wavefront per LISTED Goldilocks-Poseidon permutation of this rank's blocks: the prologues' (every owned proof), then - Goldilocks
@@ -241,7 +245,7 @@ struct h2w_plan {
     TemplateTable tt; DeviceTables dt; StrandTable st; FrParams P;
     Derived d; ProofLayout pl;
     uint64_t nrec = 0, ncells = 0, rec_cells = 0;
-    LoadItem *d_items = nullptr; uint32_t n_items = 0; uint64_t load_nrec = 0, load_ncell = 0;
+    LoadItem *d_items = nullptr; uint32_t n_items = 0, n_cap_items = 0; uint64_t load_nrec = 0, load_ncell = 0;      // d_items: the load phase's items, then the cap hashes'
     h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
@@ -279,14 +283,14 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
     pl->shape = s; pl->device = device_id; pl->P = fr_params_init(); pl->h_consts = *consts;
     pl->d = derive_shape(s); pl->pl = proof_layout(s, pl->d);
     memset(&pl->st, 0, sizeof(pl->st)); pl->st.first_zero_kind = -1; pl->st.first_zero_unit = -1;
-    std::vector<uint64_t> unit_cell; std::vector<LoadItem> items;
+    std::vector<uint64_t> unit_cell; std::vector<LoadItem> items, cap_items;
     // host inverse table
     std::vector<fr_t> inv(2 * INV_TAB, fr_zero());
     for (int k2 = 1; k2 < INV_TAB; k2++) { inv[k2] = fr_inv(fr_from_u64((uint64_t)k2), pl->P); inv[INV_TAB + k2] = fr_neg(inv[k2]); }
     // shape compile: sequential replay with the counting sink on an all-zero proof
     std::vector<uint64_t> meta; std::vector<uint64_t> zero_proof(pl->pl.total, 0);
     {
-        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st; sink.unit_cell = &unit_cell; sink.items = &items;
+        PlanSink sink; sink.meta = &meta; sink.tt = &pl->tt; sink.st = &pl->st; sink.unit_cell = &unit_cell; sink.items = &items; sink.cap_items = &cap_items;
         ValCfg cfg; cfg.proof = zero_proof.data(); cfg.mode = s.hash_mode; cfg.L = s.lookup_bits; cfg.P = pl->P;
         cfg.inv_pos = inv.data(); cfg.inv_neg = inv.data() + INV_TAB; cfg.st = nullptr; cfg.split = false; cfg.split_bn = false; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0;
         ValBackend<PlanSink> be(sink, cfg, false);
@@ -294,7 +298,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         ChallengeBlock<ValBackend<PlanSink>> *cb = new ChallengeBlock<ValBackend<PlanSink>>();
         V.run_all(*cb);
         delete cb;
-        pl->n_items = (uint32_t)items.size();
+        pl->n_items = (uint32_t)items.size(); pl->n_cap_items = s.hash_mode == 1 ? (uint32_t)cap_items.size() : 0;
         if (!items.empty()) {   // records / cells of the load phase: from the first item to the end of the last one
             // the load phase starts right after the 12 zero-state constants and is contiguous in records and cells
             const LoadItem &last = items.back();
@@ -335,6 +339,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         if (pl->dt.upload(pl->tt) != 0) return -1;
         H2W_HIP(hipMalloc((void **)&pl->d_meta, meta.size() * sizeof(uint64_t)));
         H2W_HIP(hipMemcpy(pl->d_meta, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (pl->n_cap_items) items.insert(items.end(), cap_items.begin(), cap_items.end());
         if (!items.empty()) {
             H2W_HIP(hipMalloc((void **)&pl->d_items, items.size() * sizeof(LoadItem)));
             H2W_HIP(hipMemcpy(pl->d_items, items.data(), items.size() * sizeof(LoadItem), hipMemcpyHostToDevice));
@@ -390,12 +395,13 @@ uint64_t h2w_plan_num_chain_cells(const h2w_plan *p) {      // cells of the Merk
     for (int k = 0; k < MK_KINDS; k++) n += p->st.mk_ncell[0][k] + (uint64_t)(p->shape.num_queries - 1) * p->st.mk_ncell[1][k];
     return n;
 }
-struct WsLayout { size_t recs, cbs, status, units, sbox, glp, ctr, total; };
+struct WsLayout { size_t recs, cbs, status, lflag, units, sbox, glp, ctr, total; };
 static WsLayout ws_layout(const h2w_plan *p, uint64_t n) {
     WsLayout w; size_t o = 0;
     w.recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
     w.cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
     w.status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
+    w.lflag = o; o += align_up((size_t)n * sizeof(uint32_t), 256);      // per proof: a word outside its field's range (k_prologue_load)
     w.units = o; o += align_up((size_t)n * p->st.total_unit * 4 * sizeof(fr_t), 256);                  // PoseidonBN254 unit states (values phase -> emission)
     w.sbox = o; o += align_up((size_t)n * p->st.total_unit * BN_PARTIAL_ROUNDS * 3 * sizeof(fr_t), 256);   // ... and the S-box values of their partial rounds
     w.glp = o; o += align_up((size_t)n * p->st.total_glp * GLP_LIST_WORDS * sizeof(uint64_t), 256);     // listed Goldilocks-Poseidon permutations
@@ -510,7 +516,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.cbs = (DevCB *)(ws + wl.cbs); A.status = (uint32_t *)(ws + wl.status);
     A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
     A.bn_tab = p->d_bn_tab;
-    A.load_items = p->d_items; A.n_load_items = p->n_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell;
+    A.load_items = p->d_items; A.n_load_items = p->n_items; A.n_cap_items = p->n_cap_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell; A.load_flag = (uint32_t *)(ws + wl.lflag);
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
     A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p);
     A.sh.n_own_units = (uint32_t)own_count(n_proofs * (uint64_t)p->shape.num_queries, sh.rank, sh.world);
@@ -531,8 +537,14 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     bool forked = false;
     auto body = [&]() -> int {
         H2W_HIP(hipEventRecord(ev[0], stream));
+        // 0. witness load + cap-hash limb decompositions: one lane per (proof, item)
+        H2W_HIP(hipMemsetAsync(A.load_flag, 0, n_proofs * sizeof(uint32_t), stream));
+        if (p->n_items + p->n_cap_items) {
+            const dim3 lgrid((p->n_items + p->n_cap_items + 255) / 256, (unsigned)n_proofs);
+            if (cm.starts) hipLaunchKernelGGL(k_prologue_load<true>, lgrid, dim3(256), 0, stream, A); else hipLaunchKernelGGL(k_prologue_load<false>, lgrid, dim3(256), 0, stream, A);
+        }
         // 1. prologue strands, values: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks
-        if (cm.starts) hipLaunchKernelGGL(k_prologue_values<true>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_prologue_values<false>, dim3((unsigned)n_proofs), dim3(64), 0, stream, A);
+        launch_prologue_values(A, stream);
         H2W_HIP(hipEventRecord(ev[9], stream));
         // 2. the records of the listed Goldilocks-Poseidon permutations: with PoseidonBN254 caps the prologues' (now); with Goldilocks caps
         //    together with the Merkle strands' (below)
@@ -855,8 +867,11 @@ int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, u
     const WsLayout wl = ws_layout(p, n_proofs);
     DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
+    std::vector<uint32_t> flag((size_t)n_proofs);
     H2W_HIP(hipMemcpyAsync(host_status, (const char *)workspace_dev + wl.status, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    H2W_HIP(hipMemcpyAsync(flag.data(), (const char *)workspace_dev + wl.lflag, n_proofs * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     H2W_HIP(hipStreamSynchronize(stream));
+    for (uint64_t i = 0; i < n_proofs; i++) if (!host_status[i]) host_status[i] = flag[i];      // (the strands' conditions come first, as in round 2)
     return 0;
 }
 int h2w_advice_digest(const void *advice_dev, uint64_t n_cells, uint64_t *digest4_dev, void *stream_) {

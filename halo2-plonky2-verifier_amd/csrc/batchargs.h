@@ -1,6 +1,7 @@
 // batchargs.h - kernel arguments of the batched hot path, shared by its translation units (batch.hip, glue.hip).
 #pragma once
 #include "valbackend.h"
+#include "coop.h"
 
 namespace h2w {
 
@@ -31,7 +32,7 @@ struct BatchArgs {
     fr_t *unit_sbox;                // [nproofs][st.total_unit][56][3]: canonical x^2, x^4, x^5 of its partial rounds' S-boxes
     uint64_t *glp_list;             // [nproofs][st.total_glp][GLP_LIST_WORDS]: the listed Goldilocks-Poseidon permutations (values phase -> record emission)
     int glp_small_mds;
-    const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
+    const LoadItem *load_items; uint32_t n_load_items, n_cap_items; uint64_t load_nrec, load_ncell; uint32_t *load_flag;      // load_items: n_load_items of the load phase, then n_cap_items cap hashes
     ColMap cm;      // column-major emission (starts == nullptr: flat advice)
     ShardMap sh;
 };
@@ -63,11 +64,18 @@ __device__ __forceinline__ fr_t *block_out(const BatchArgs &A, int p, int q) {
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
     c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = &A.st; c.split = true;
-    c.load_items = A.load_items; c.n_load_items = A.n_load_items; c.load_nrec = A.load_nrec; c.load_ncell = A.load_ncell;
+    c.load_items = A.load_items; c.n_load_items = A.n_load_items; c.n_cap_items = A.n_cap_items; c.load_nrec = A.load_nrec; c.load_ncell = A.load_ncell;
     c.split_bn = false;
     return c;
 }
 
+template <bool COLS, bool VALPH, int HM> __device__ __forceinline__ void coop_sink_init(CoopSinkT<COLS, VALPH, HM> &sink, const BatchArgs &A, int p, int q) {
+    sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.lane = threadIdx.x; sink.cc.init(A.cm);
+    sink.glp = A.glp_list + (uint64_t)p * A.st.total_glp * GLP_LIST_WORDS; sink.small_mds = A.glp_small_mds != 0;
+    sink.bind_lds();
+}
+
 void launch_glue_strands(const BatchArgs &A, hipStream_t stream);      // glue.hip
+void launch_prologue_values(const BatchArgs &A, hipStream_t stream);   // glue.hip
 
 }  // namespace h2w

@@ -13,7 +13,7 @@
 namespace h2w {
 
 struct CountSink {       // host: lays out the instance (record metas, cell count)
-    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = -1;
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false, kDevSponge = false; static constexpr int kHashMode = -1;
     const TemplateTable *tt; std::vector<uint64_t> meta; uint64_t cell_off = 0;
     void rec(int t, uint64_t, uint64_t, uint64_t, uint64_t) { meta.push_back(meta_pack((uint32_t)t, cell_off)); cell_off += (uint64_t)tt->ncells(t); }
     void cell(const fr_t &) { cell_off++; }

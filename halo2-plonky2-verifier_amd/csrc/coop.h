@@ -37,6 +37,7 @@ __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)
 // ds_read (a namespace-scope __shared__ array keeps the LDS address space; a pointer member would decay to flat).
 __shared__ uint64_t s_glp_k[GLP_CONST_WORDS];
 __shared__ uint64_t s_glp_a[SPONGE_WIDTH], s_glp_b[SPONGE_WIDTH];      // the permutation's state exchange buffers
+__shared__ uint64_t s_glp_in[CH_BUF];                                  // the challenger's input buffer (values phase of the prologue)
 __shared__ uint64_t s_glp_m[SPONGE_WIDTH * SPONGE_WIDTH];              // MDS as a dense matrix, row-major: M[r][j] = circ[(j - r) mod 12] + [j == r] diag[r]  (values phase)
 // LDS pointers are handed to the (out-of-line) permutation through the sink: a __shared__ array that several kernels use is reached
 // from a non-kernel function through llvm.amdgcn.lds.offset.table - a GLOBAL load of the offset at every use, i.e. a vmcnt(0) wait
@@ -77,56 +78,77 @@ template <int N> __device__ __forceinline__ uint64_t row_shr64(uint64_t v) {    
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x110 + N, 0xf, 0xf, true);
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t gl_sbox7(uint64_t x) { const uint64_t x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x6 = gl_mul(x4, x2); return gl_mul(x6, x); }
+// Goldilocks arithmetic of the values phase: operands and results are any 64-bit representatives (x mod p for some x < 2^64), made canonical
+// once, at the end of the permutation - the record-emitting kernels are the ones that need canonical values
+__device__ __forceinline__ uint64_t glz_reduce(u128 x) {      // x (any 128 bits) mod p, up to a multiple of p: 2^64 = 2^32 - 1, 2^96 = -1 (mod p)
+    const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64), hh = hi >> 32, hl = hi & GL_EPS;
+    uint64_t t0 = lo - hh; if (lo < hh) t0 -= GL_EPS;
+    const uint64_t t1 = hl * GL_EPS; uint64_t r = t0 + t1; if (r < t1) r += GL_EPS;
+    return r;
+}
+__device__ __forceinline__ uint64_t glz_mul(uint64_t a, uint64_t b) { return glz_reduce((u128)a * b); }
+__device__ __forceinline__ uint64_t glz_muladd(uint64_t a, uint64_t b, uint64_t c) { return glz_reduce((u128)a * b + c); }
+__device__ __forceinline__ uint64_t glz_add(uint64_t a, uint64_t b) {      // a + b with a canonical or b canonical (the sum wraps at most once, and then r + eps does not wrap again)
+    uint64_t r = a + b; if (r < a) r += GL_EPS; return r;
+}
+__device__ __forceinline__ uint64_t glz_add2(uint64_t a, uint64_t b) {     // any two representatives
+    uint64_t r = a + b; if (r < a) { r += GL_EPS; if (r < GL_EPS) r += GL_EPS; } return r;
+}
 // Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES: lane l < 12 holds state element l and
 // returns its element of the output.  K: the constant block in LDS, M: the dense MDS rows (stage_glp_consts).
 __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64_t *M, int l, bool small) {
     const int lc = l < SPONGE_WIDTH ? l : SPONGE_WIDTH - 1, lm = lc > 0 ? lc - 1 : 0;
     auto full_round = [&](int rc) {
-        x = gl_sbox7(gl_add(x, K[KO_ARC + SPONGE_WIDTH * rc + lc]));
+        x = glz_add(x, K[KO_ARC + SPONGE_WIDTH * rc + lc]);
+        { const uint64_t x2 = glz_mul(x, x), x3 = glz_mul(x2, x), x4 = glz_mul(x2, x2); x = glz_mul(x3, x4); }      // x^7
         if (small) {
             uint64_t lo = 0, hi = 0;
 #pragma unroll
             for (int j = 0; j < SPONGE_WIDTH; j++) { const uint64_t sj = readlane64(x, j); const uint32_t m = (uint32_t)M[lc * SPONGE_WIDTH + j]; lo += (uint64_t)m * (uint32_t)sj; hi += (uint64_t)m * (uint32_t)(sj >> 32); }
-            x = gl_reduce128((u128)lo + ((u128)hi << 32));
+            x = glz_reduce((u128)lo + ((u128)hi << 32));
         } else {
             uint64_t acc = 0;
 #pragma unroll
-            for (int j = 0; j < SPONGE_WIDTH; j++) acc = gl_muladd(M[lc * SPONGE_WIDTH + j], readlane64(x, j), acc);
+            for (int j = 0; j < SPONGE_WIDTH; j++) acc = glz_muladd(M[lc * SPONGE_WIDTH + j], readlane64(x, j), acc);
             x = acc;
         }
     };
 #pragma unroll 1
     for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(i);
-    x = gl_add(x, K[KO_FIRST + lc]);                                                     // partial_first_constant_layer
+    x = glz_add(x, K[KO_FIRST + lc]);                                                    // partial_first_constant_layer
     {   // mds_partial_layer_init: element 0 stays, element c >= 1 = sum_r init[r-1][c-1] s_r
         uint64_t res = 0;
 #pragma unroll
-        for (int r = 1; r < SPONGE_WIDTH; r++) res = gl_muladd(K[KO_INIT + (r - 1) * 11 + lm], readlane64(x, r), res);
+        for (int r = 1; r < SPONGE_WIDTH; r++) res = glz_muladd(K[KO_INIT + (r - 1) * 11 + lm], readlane64(x, r), res);
         x = l == 0 ? x : res;
     }
+    const uint64_t m00 = K[KO_CIRC] + K[KO_DIAG];
 #pragma unroll 1
     for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
-        const uint64_t y = gl_add(gl_sbox7(x), K[KO_PRC + r]);                            // (lane 0's is the one that counts)
-        const uint64_t s0 = readlane64(y, 0);
-        // d = (circ0 + diag0) s0 + sum_i w_hat_i s_i: one product per lane, summed by a row scan
-        const uint64_t t = l == 0 ? K[KO_CIRC] + K[KO_DIAG] : K[KO_WHAT + r * 11 + lm];
-        uint64_t term = gl_mul(t, l == 0 ? s0 : x); if (l >= SPONGE_WIDTH) term = 0;
-        term = gl_add_c(term, row_shr64<1>(term)); term = gl_add_c(term, row_shr64<2>(term));
-        term = gl_add_c(term, row_shr64<4>(term)); term = gl_add_c(term, row_shr64<8>(term));
+        // One instruction stream, two jobs per product: lane 0 walks its S-box (x^7 = x^3 x^4), the other lanes form their terms w_hat_i s_i of the
+        // sparse row beside its first product; s0' = s0^7 + c; then lane 0: (circ0 + diag0) s0', lanes i: s_i + v_i s0' in one multiply-add
+        const uint64_t wh = K[KO_WHAT + r * 11 + lm];
+        const uint64_t p1 = glz_mul(x, l == 0 ? x : wh);                                    // lane 0: s0^2 | lanes i: w_hat_i s_i
+        const uint64_t x2 = readlane64(p1, 0), s0 = readlane64(x, 0);
+        const uint64_t x3 = glz_mul(x2, s0), x4 = glz_mul(x2, x2);                         // (the same on every lane)
+        const uint64_t s0n = glz_add(glz_mul(x3, x4), K[KO_PRC + r]);
+        const uint64_t p2 = glz_muladd(l == 0 ? m00 : K[KO_VS + r * 11 + lm], s0n, l == 0 ? 0 : x);      // lane 0: m00 s0' | lanes i: the new s_i
+        // d = m00 s0' + sum_i w_hat_i s_i: a row scan
+        uint64_t term = l == 0 ? p2 : p1; if (l >= SPONGE_WIDTH) term = 0;
+        term = glz_add2(term, row_shr64<1>(term)); term = glz_add2(term, row_shr64<2>(term));
+        term = glz_add2(term, row_shr64<4>(term)); term = glz_add2(term, row_shr64<8>(term));
         const uint64_t d = readlane64(term, SPONGE_WIDTH - 1);
-        const uint64_t nx = gl_muladd(K[KO_VS + r * 11 + lm], s0, x);
-        x = l == 0 ? d : nx;
+        x = l == 0 ? d : p2;
     }
 #pragma unroll 1
     for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + i);
-    return x;
+    return x >= GL_P ? x - GL_P : x;
 }
 constexpr int GLP_LIST_WORDS = 1 + SPONGE_WIDTH;            // one listed permutation: {index of its first record, input state}
 
 // VALPH: the values phase of a strand (see the top of the file); false: the record-emitting permutation (k_glp_emit)
 template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
-    static constexpr bool kCoop = true, kSplitOnly = false, kBnUnits = false; static constexpr int kHashMode = HASH_MODE;
+    static constexpr bool kCoop = true, kSplitOnly = false, kBnUnits = false, kDevSponge = VALPH; static constexpr int kHashMode = HASH_MODE;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; ColPolicy<COLS> cc;
     lds64_t *lk = nullptr, *la = nullptr, *lb = nullptr, *lm = nullptr;      // s_glp_k, s_glp_a, s_glp_b, s_glp_m of the running kernel (set by bind_lds)
     uint64_t *glp = nullptr; uint32_t glp_slot = 0; bool small_mds = false;   // values phase: this proof's permutation list, the next slot of this strand
@@ -136,15 +158,9 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         if (lane == 0 && emit) g_store_rec(recs + nrec, a, b, c, d);
         nrec++; cell_off += ncells[t];
     }
-    bool lane_mode = false, lane_on = false;     // lane_mode: every enabled lane writes cells at its OWN offset (coop_decompose_hashes)
-    __device__ __forceinline__ void cell(const fr_t &v) { if ((lane_mode ? lane_on : lane == 0) && emit) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
+    __device__ __forceinline__ void cell(const fr_t &v) { if (lane == 0 && emit) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
-    __device__ int coop_lanes() { return 64; }
-    __device__ int coop_lane() { return lane; }
-    __device__ uint64_t lane_bcast(uint64_t v, int src) { return __shfl(v, src, 64); }
-    __device__ void begin_lane_cells(uint64_t off, bool on) { cell_off = off; lane_mode = true; lane_on = on; }
-    __device__ void end_lane_cells(uint64_t off) { cell_off = off; lane_mode = false; }
     __device__ __forceinline__ void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     __device__ void merkle_begin(int, int, bool, uint64_t) {}
     __device__ void merkle_end(int, int, bool) {}
@@ -155,22 +171,57 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
     __device__ void glp_note() {}
     __device__ void note_load(uint64_t, int) {}
     __device__ bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
-    // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294): every item is independent -> striped over the lanes
-    uint32_t load_flag = 0;      // set by coop_load_proof: some word is outside its field's canonical range (status 4)
-    __device__ __noinline__ bool coop_load_proof(const ValCfg &cfg) {
-        bool bad = false;
-        for (uint32_t i = lane; i < cfg.n_load_items; i += 64) {
-            const uint64_t *ip = reinterpret_cast<const uint64_t *>(cfg.load_items + i);
-            const uint64_t wk = g_load_u64(ip), irec = g_load_u64(ip + 1), icell = g_load_u64(ip + 2);
-            const uint32_t word = (uint32_t)wk, kind = (uint32_t)(wk >> 32);
-            const uint64_t *w = cfg.proof + word; const uint64_t w0 = g_load_u64(w);
-            if (kind <= 1) { if (emit) g_store_rec(recs + irec, w0, 0, 0, 0); bad |= w0 >= GL_P; }
-            else if (kind == 2) { const uint64_t w1 = g_load_u64(w + 1), w2 = g_load_u64(w + 2), w3 = g_load_u64(w + 3); if (emit) g_store_rec(recs + irec, w0, w1, w2, w3); bad |= w0 >= GL_P || w1 >= GL_P || w2 >= GL_P || w3 >= GL_P; }
-            else { fr_t v; v.l[0] = w0; v.l[1] = g_load_u64(w + 1); v.l[2] = g_load_u64(w + 2); v.l[3] = g_load_u64(w + 3); if (emit) g_store_fr(out + cc.map(icell), v); bad |= fr_geq_mod(v); }
+    __device__ void note_cap_hash(uint64_t) {}
+    // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294) and the limb decompositions of the caps' BN254 hashes are k_prologue_load's
+    // (every item is independent: one lane each); the strand only steps over their records and cells
+    __device__ __forceinline__ bool coop_load_proof(const ValCfg &cfg) { nrec += cfg.load_nrec; cell_off += cfg.load_ncell; return true; }
+    // ---- the Fiat-Shamir sponge of the values phase (ChallengerChip, challenger/mod.rs:19-126; overwrite-mode duplex, rate 8): the state
+    // lives on the lanes (lane l: element l), the input buffer in LDS; every permutation is listed for k_glp_emit
+    uint64_t sx = 0; int sp_in = 0, sp_out = 0; lds64_t *lin = nullptr;
+    __device__ __forceinline__ void sponge_init() { sx = 0; sp_in = sp_out = 0; lin = (lds64_t *)s_glp_in; }
+    __device__ __forceinline__ bool sponge_observe(uint64_t t) { sp_out = 0; if (sp_in >= CH_BUF) return false; lin[sp_in++] = t; return true; }
+    template <class WordFn> __device__ __forceinline__ bool sponge_observe_words(const uint64_t *proof, int n, WordFn word) {      // n proof words, one lane each
+        sp_out = 0; if (sp_in + n > CH_BUF) return false;
+        for (int base = 0; base < n; base += 64) { const int i = base + lane; if (i < n) lin[sp_in + i] = g_load_u64(proof + word(i)); }
+        sp_in += n; return true;
+    }
+    // observe_cap (challenger/mod.rs:65-74): hash j of the cap on lane j; Goldilocks hashes are their 4 words, BN254 hashes 5 limbs of 56 bits
+    // (HashWire::to_goldilocks_vec, hash/poseidon_bn254/hash.rs:31-43: decompose_le(56, 5) - its cells are k_prologue_load's)
+    __device__ __noinline__ bool sponge_observe_cap(const uint64_t *proof, uint64_t w0, int n, int mode, int L) {
+        const int per = mode == 0 ? 4 : 5;
+        sp_out = 0; if (sp_in + per * n > CH_BUF) return false;
+        for (int base = 0; base < n; base += 64) {
+            const int j = base + lane;
+            if (j < n) {
+                fr_t x; for (int i = 0; i < 4; i++) x.l[i] = g_load_u64(proof + w0 + 4ull * j + i);
+                if (mode == 0) for (int i = 0; i < 4; i++) lin[sp_in + 4 * j + i] = x.l[i];
+                else for (int t = 0; t < 5; t++) lin[sp_in + 5 * j + t] = fr_bits(x, 56 * t, 56);
+            }
         }
-        if (__any(bad)) load_flag = 4;
-        nrec += cfg.load_nrec; cell_off += cfg.load_ncell;
+        sp_in += per * n;
+        if (mode == 1) { const int nl = (56 + L - 1) / L, rem = 56 % L; cell_off += (uint64_t)n * (13 + 5ull * ((nl > 1 ? 1 + 3 * (nl - 1) : 0) + (rem ? 4 : 0))); }
         return true;
+    }
+    __device__ __forceinline__ void sponge_permute() {
+        // list the permutation (lane 0: where its records start; lanes 1..12: the input state), then its values
+        const uint64_t up = __shfl_up(sx, 1, 64), w = lane == 0 ? nrec : up;
+        if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
+        glp_slot++;
+        sx = glp_permute_lanes(sx, lk, lm, lane, small_mds);
+        const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
+        nrec += GLP_RECS;
+        cell_off += 2 * HALF_N_FULL_ROUNDS * (12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA)) + 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
+    }
+    __device__ __noinline__ uint64_t sponge_challenge() {                      // ChallengerChip::get_challenge (:92-108, :260-277)
+        if (sp_in) {
+            for (int off = 0; off < sp_in; off += SPONGE_RATE) {
+                const int len = sp_in - off < SPONGE_RATE ? sp_in - off : SPONGE_RATE;
+                if (lane < len) sx = lin[off + lane];
+                sponge_permute();
+            }
+            sp_in = 0; sp_out = SPONGE_RATE;
+        } else if (sp_out == 0) { sponge_permute(); sp_out = SPONGE_RATE; }
+        return readlane64(sx, --sp_out);
     }
 
     __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
@@ -415,7 +466,7 @@ constexpr BnSrc bn_map_partial(int c) {
 
 enum { QUAD_VALUES = 1, QUAD_EMIT = 2, QUAD_FUSED = 3 };      // QUAD_FUSED: one quad walks its strand AND emits every unit of it (one pass, serial in the path's depth)
 template <bool COLS, int MODE> struct QuadSinkT {
-    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = true; static constexpr int kHashMode = 1;
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = true, kDevSponge = false; static constexpr int kHashMode = 1;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int l4; ColPolicy<COLS> cc;
     fr_t *ustate;                  // output states of this strand's permutation units, [unit][4] (written by QUAD_VALUES, read by QUAD_EMIT)
     fr_t *sbx;                     // the S-box chains of their partial rounds, [unit][BN_PARTIAL_ROUNDS][3] = canonical x^2, x^4, x^5 (QUAD_VALUES -> QUAD_EMIT)
@@ -430,11 +481,7 @@ template <bool COLS, int MODE> struct QuadSinkT {
     __device__ __forceinline__ void cell(const fr_t &v) { if (MODE != QUAD_VALUES && l4 == 0 && act) g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     __device__ __forceinline__ void gate() {}
     __device__ __forceinline__ void lookup() {}
-    __device__ int coop_lanes() { return 1; }
-    __device__ int coop_lane() { return 0; }
-    __device__ uint64_t lane_bcast(uint64_t v, int) { return v; }
-    __device__ void begin_lane_cells(uint64_t, bool) {}
-    __device__ void end_lane_cells(uint64_t) {}
+    __device__ void note_cap_hash(uint64_t) {}
     __device__ __forceinline__ void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     __device__ void merkle_begin(int, int, bool, uint64_t) {}
     __device__ void merkle_end(int, int, bool) {}

@@ -1,8 +1,10 @@
-// glue.hip - the query glue strands of the batched hot path: FriChip::verify_query_round minus its Merkle proofs
-// (fri/mod.rs:338-444: index bits, subgroup_x, combine_initial, per fold step the consistency select, compute_evaluation /
-// interpolate_coset and x^arity, final-polynomial evaluation), one lane per (proof, query).
+// glue.hip - the two strand kernels that are serial programs of Goldilocks gadget operations:
+//   k_strands          the query glue: FriChip::verify_query_round minus its Merkle proofs (fri/mod.rs:338-444: index bits, subgroup_x,
+//                      combine_initial, per fold step the consistency select, compute_evaluation / interpolate_coset and x^arity,
+//                      final-polynomial evaluation), one lane per (proof, query);
+//   k_prologue_values  the prologue on values (stark/mod.rs:497-508, challenger/mod.rs:168-222, fri/mod.rs:45-62,130-145), one wavefront per proof.
 //
-// Its own translation unit because the gadget stack is compiled FLATTENED here (H2W_FLATTEN_CHIPS): a strand is a serial program of
+// Their own translation unit because the gadget stack is compiled FLATTENED here (H2W_FLATTEN_CHIPS): a strand is a serial program of
 // a few thousand Goldilocks ops, each of which appends one 32-byte block record.  Out of line, every op is an AMDGPU function call:
 // it starts with s_waitcnt vmcnt(0) - i.e. it waits for the record store of the PREVIOUS op to be acknowledged by memory - and
 // reaches the sink's cursor (record index, cell offset) through flat loads of the backend object (profiles/: 5.3 ms for 5.5 k ops
@@ -25,6 +27,26 @@ template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) v
     Verifier<GlueB> V(be, A.shape, A.consts);
     V.query_round(q, cb);
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+
+// one wavefront per proof: wave-uniform gadget code; every rank of a sharded run computes every prologue's VALUES (it needs the
+// challenges); only the proof's owner writes the block (direct cells, records, permutation list)
+template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_prologue_values(BatchArgs A) {
+    typedef CoopSinkT<COLS, true> Sink; typedef ValBackend<Sink> CoopB;
+    __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
+    stage_glp_consts(A.consts, threadIdx.x, 64);
+    const int p = blockIdx.x;
+    Sink sink; coop_sink_init(sink, A, p, -1); sink.nrec = 0; sink.cell_off = 0; sink.glp_slot = 0;
+    sink.emit = own_prologue(A, p);
+    CoopB be(sink, make_cfg(A, p), true);
+    Verifier<CoopB> V(be, A.shape, A.consts);
+    V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
+    if (threadIdx.x == 0) A.status[p] = be.status;
+}
+
+void launch_prologue_values(const BatchArgs &A, hipStream_t stream) {
+    if (A.cm.starts) hipLaunchKernelGGL(k_prologue_values<true>, dim3((unsigned)A.nproofs), dim3(64), 0, stream, A);
+    else hipLaunchKernelGGL(k_prologue_values<false>, dim3((unsigned)A.nproofs), dim3(64), 0, stream, A);
 }
 
 void launch_glue_strands(const BatchArgs &A, hipStream_t stream) {

@@ -32,7 +32,7 @@ HF uint64_t strand_q_rec(const StrandTable &t, int q) { return q == 0 ? t.q_rec0
 HF uint64_t strand_q_cell(const StrandTable &t, int q) { return q == 0 ? t.q_cell0[0] : t.q_cell0[1] + (uint64_t)(q - 1) * t.q_ncell[1]; }
 
 // one witness-load item of WitnessChip::load_proof_with_pis (built by the shape compiler; consumed by the cooperative loader)
-struct LoadItem { uint32_t word; uint32_t kind; uint64_t rec; uint64_t cell; };   // kind 0: GL load_witness, 1: GL 1-cell, 2: GL hash (4 const cells), 3: BN254 hash (1 cell)
+struct LoadItem { uint32_t word; uint32_t kind; uint64_t rec; uint64_t cell; };   // kind 0: GL load_witness, 1: GL 1-cell, 2: GL hash (4 const cells), 3: BN254 hash (1 cell), 4: limb decomposition of a BN254 cap hash (challenger/mod.rs:65-74)
 
 struct ValCfg {
     const uint64_t *proof;           // this proof's flat words
@@ -43,12 +43,14 @@ struct ValCfg {
     bool split;                      // true: merkle calls are skipped (their cells belong to merkle strands)
     bool split_bn;                   // true: the sink emits a PoseidonBN254 permutation's cells itself (QuadSink::bn_emit_inline)
     const LoadItem *load_items; uint32_t n_load_items; uint64_t load_nrec, load_ncell;
+    uint32_t n_cap_items;            // ... followed by n_cap_items items of kind 4
 };
 
 template <class Sink> struct ValBackend {
     typedef uint64_t Gl; typedef uint64_t Bool; typedef fr_t Fr; typedef u128 Big;
     static constexpr bool kCoopPoseidon = Sink::kCoop;
     static constexpr bool kSplitOnly = Sink::kSplitOnly;       // the backend only ever runs strands whose Merkle proofs are other strands
+    static constexpr bool kDevSponge = Sink::kDevSponge;       // the Fiat-Shamir sponge is kept by the sink (device prologue wavefront)
     static constexpr bool kBnUnits = Sink::kBnUnits;           // every PoseidonBN254 permutation of this backend is a unit handled by the sink
     static constexpr int kHashMode = Sink::kHashMode;          // >= 0: the only hash mode this backend is ever run with (-1: the shape's)
     HF int md() const { if constexpr (kHashMode >= 0) return kHashMode; else return cfg.mode; }
@@ -204,20 +206,13 @@ template <class Sink> struct ValBackend {
     }
     HF void bn_perm_begin() { sink.bn_perm_begin(zero_cached); }
     HF void bn_perm_end() { sink.bn_perm_end(zero_cached); unit_idx++; }
-    // ---------------------------------------------------------------- cooperative cap decomposition (see Verifier::observe_cap)
-    HF int coop_lanes() { return sink.coop_lanes(); }
-    HF Gl lane_bcast(Gl v, int src) { return sink.lane_bcast(v, src); }
-    HF void coop_decompose_hashes(uint64_t w0, int n, Gl *limbs) {
-        const int me = sink.coop_lane();
-        const uint64_t cell0 = sink.cell_off;                       // RangeChip::decompose_le(x, 56, 5): 13 + 5 range checks
-        const int L = cfg.L, nl = (56 + L - 1) / L, rem = 56 % L;
-        const uint64_t per = 13 + 5ull * ((nl > 1 ? 1 + 3 * (nl - 1) : 0) + (rem ? 4 : 0));
-        sink.begin_lane_cells(cell0 + per * (uint64_t)me, me < n);
-        Fr x = fr_zero();
-        if (me < n) for (int i = 0; i < 4; i++) x.l[i] = pw(w0 + 4ull * me + i);
-        decompose_le_56_5(x, limbs);
-        sink.end_lane_cells(cell0 + per * (uint64_t)n);
-    }
+    // ---------------------------------------------------------------- the sponge of a device prologue wavefront (kDevSponge; coop.h)
+    HF void note_cap_hash(uint64_t w) { sink.note_cap_hash(w); }      // a cap hash is about to be decomposed into limbs (the shape compiler lists it for the load kernel)
+    HF void sponge_init() { sink.sponge_init(); }
+    HF void sponge_observe(Gl t) { if (!sink.sponge_observe(t)) fail(3); }
+    template <class WordFn> HF void sponge_observe_words(int n, WordFn word) { if (!sink.sponge_observe_words(cfg.proof, n, word)) fail(3); }
+    HF void sponge_observe_cap(uint64_t w0, int n) { if (!sink.sponge_observe_cap(cfg.proof, w0, n, md(), cfg.L)) fail(3); }
+    HF Gl sponge_challenge() { return sink.sponge_challenge(); }
     // ---------------------------------------------------------------- strand hooks
     HF bool merkle_split(int q, int kind) {
         if (!cfg.split) return false;
@@ -235,7 +230,7 @@ template <class Sink> struct ValBackend {
 
 // device sink: records into this proof's record array, direct cells into this proof's advice range
 template <bool COLS, bool SPLIT_ONLY = false> struct DevSinkT {
-    static constexpr bool kCoop = false, kSplitOnly = SPLIT_ONLY, kBnUnits = false; static constexpr int kHashMode = -1;
+    static constexpr bool kCoop = false, kSplitOnly = SPLIT_ONLY, kBnUnits = false, kDevSponge = false; static constexpr int kHashMode = -1;
     HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; ColPolicy<COLS> cc;
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }
@@ -251,13 +246,9 @@ template <bool COLS, bool SPLIT_ONLY = false> struct DevSinkT {
     HF void bn_perm_end(bool) {}
     HF void glp_note() {}
     HF void note_load(uint64_t, int) {}
+    HF void note_cap_hash(uint64_t) {}
     HF bool coop_load_proof(const ValCfg &) { return false; }
     HF bool bn_emit_inline(fr_t *, const ValCfg &, bool &) { return false; }
-    HF int coop_lanes() { return 1; }
-    HF int coop_lane() { return 0; }
-    HF uint64_t lane_bcast(uint64_t v, int) { return v; }
-    HF void begin_lane_cells(uint64_t, bool) {}
-    HF void end_lane_cells(uint64_t) {}
 };
 typedef DevSinkT<false> DevSink;
 

@@ -7,6 +7,7 @@
 //     merkle   (per query x tree) : MerkleTreeChip::verify_proof_to_cap_with_cap_index
 // A sequential backend (plan / eager ABI) runs them in the reference order; the device runs one lane per strand.
 #pragma once
+#include <type_traits>
 #include "chips.h"
 
 namespace h2w {
@@ -23,24 +24,43 @@ template <class B> struct ChallengeBlock {
 };
 
 // =========================================================================== ChallengerChip (challenger/mod.rs)
+// B::kDevSponge: the sponge lives in the backend's sink (the device prologue wavefront keeps the duplex state on its lanes and the input
+// buffer in LDS, coop.h); otherwise here, as the reference's struct does.
 template <class B> struct ChallengerChip {
     typedef typename B::Gl Gl; typedef HashW<B> H;
     B &be; PoseidonPermutationChip<B> pg; HasherChip<B> &hs;
-    Gl state[SPONGE_WIDTH]; Gl in[CH_BUF]; int n_in; Gl out[SPONGE_RATE]; int n_out;
+    struct Buffers { Gl state[SPONGE_WIDTH]; Gl in[CH_BUF]; Gl out[SPONGE_RATE]; }; struct NoBuffers {};
+    typename std::conditional<B::kDevSponge, NoBuffers, Buffers>::type m; int n_in, n_out;
     HF ChallengerChip(B &b, HasherChip<B> &h, const h2w_poseidon_consts_t *k) : be(b), pg(b, k), hs(h), n_in(0), n_out(0) {}
-    HF void observe_element(Gl t) { n_out = 0; if (n_in < CH_BUF) in[n_in++] = t; else be.fail(3); }     // :45-50
+    HF void load_zero_state() {                                                                         // stark/mod.rs:497-499 (permutation_chip.load_zero)
+        if constexpr (B::kDevSponge) { Gl z[SPONGE_WIDTH]; pg.load_zero(z); be.sponge_init(); } else pg.load_zero(m.state);
+    }
+    HF void observe_element(Gl t) {                                                                     // :45-50
+        if constexpr (B::kDevSponge) be.sponge_observe(t);
+        else { n_out = 0; if (n_in < CH_BUF) m.in[n_in++] = t; else be.fail(3); }
+    }
     HF void observe_hash(const H &h) { Gl v[5]; int n = hs.to_goldilocks_vec(h, v); for (int i = 0; i < n; i++) observe_element(v[i]); } // :59-63
     HF void observe_extension_element(const ExtW<B> &e) { observe_element(e.e[0]); observe_element(e.e[1]); }   // :76-78
+    // n extension elements that are proof words (word(i): first word of element i), in order
+    template <class WordFn> HF void observe_ext_words(int n, WordFn word) {
+        if constexpr (B::kDevSponge) be.sponge_observe_words(2 * n, [&](int j) { return word(j >> 1) + (uint64_t)(j & 1); });
+        else for (int i = 0; i < n; i++) { ExtW<B> e; e.e[0] = be.proof_gl(word(i)); e.e[1] = be.proof_gl(word(i) + 1); observe_extension_element(e); }
+    }
     HNI void absorb_buffered_inputs() {                                                                 // :260-277
-        if (n_in == 0) return;
-        pg.absorb_goldilocks(state, in, n_in);
-        for (int i = 0; i < SPONGE_RATE; i++) out[i] = state[i];
-        n_out = SPONGE_RATE; n_in = 0;
+        if constexpr (!B::kDevSponge) {
+            if (n_in == 0) return;
+            pg.absorb_goldilocks(m.state, m.in, n_in);
+            for (int i = 0; i < SPONGE_RATE; i++) m.out[i] = m.state[i];
+            n_out = SPONGE_RATE; n_in = 0;
+        }
     }
     HNI Gl get_challenge() {                                                                            // :92-108
-        absorb_buffered_inputs();
-        if (n_out == 0) { pg.permute(state); for (int i = 0; i < SPONGE_RATE; i++) out[i] = state[i]; n_out = SPONGE_RATE; }
-        return out[--n_out];
+        if constexpr (B::kDevSponge) return be.sponge_challenge();
+        else {
+            absorb_buffered_inputs();
+            if (n_out == 0) { pg.permute(m.state); for (int i = 0; i < SPONGE_RATE; i++) m.out[i] = m.state[i]; n_out = SPONGE_RATE; }
+            return m.out[--n_out];
+        }
     }
     HF ExtW<B> get_extension_challenge() { ExtW<B> r; r.e[0] = get_challenge(); r.e[1] = get_challenge(); return r; }  // :119-126
 };
@@ -98,18 +118,8 @@ template <class B> struct Verifier {
         for (int i = 0; i < s.n_pis; i++, w++) load_gl(w);                                      // public inputs (:285-288)
     }
     HF void observe_cap(ChallengerChip<B> &ch, uint64_t w0) {                                       // challenger/mod.rs:65-74
-        if (s.hash_mode == 1 && be.coop_lanes() > 1) {
-            // BN254 caps on a cooperating wavefront: lane j decomposes hash j (its 68 cells are independent of the others'),
-            // then the 5 limbs of every hash are handed to all lanes in order (the sponge buffer is wave-uniform)
-            typename B::Gl limbs[5];
-            for (int base = 0; base < d.cap_size; base += be.coop_lanes()) {
-                const int n = d.cap_size - base < be.coop_lanes() ? d.cap_size - base : be.coop_lanes();
-                be.coop_decompose_hashes(w0 + 4ull * base, n, limbs);
-                for (int j = 0; j < n; j++) for (int t = 0; t < 5; t++) ch.observe_element(be.lane_bcast(limbs[t], j));
-            }
-            return;
-        }
-        for (int i = 0; i < d.cap_size; i++) ch.observe_hash(be.proof_hash(w0 + 4ull * i));
+        if constexpr (B::kDevSponge) be.sponge_observe_cap(w0, d.cap_size);      // (the cells of the BN254 hashes' limb decompositions: the load kernel)
+        else for (int i = 0; i < d.cap_size; i++) { be.note_cap_hash(w0 + 4ull * i); ch.observe_hash(be.proof_hash(w0 + 4ull * i)); }
     }
     // openings in to_fri_openings() order (stark/mod.rs:48-69): zeta batch = local, perm_zs, quotient ; zeta_next batch = next, perm_zs_next
     HF uint64_t zeta_word(int i) const {
@@ -126,7 +136,7 @@ template <class B> struct Verifier {
     // ---- prologue strand
     HF void prologue(ChallengeBlock<B> &cb) {
         ChallengerChip<B> ch(be, hs, k);
-        ch.pg.load_zero(ch.state);                                   // stark/mod.rs:497-499
+        ch.load_zero_state();                                        // stark/mod.rs:497-499
         load_proof_with_pis();                                       // stark/mod.rs:506
         // ChallengerChip::get_stark_challenges (challenger/mod.rs:167-222)
         observe_cap(ch, pl.trace_cap);
@@ -138,12 +148,12 @@ template <class B> struct Verifier {
         observe_cap(ch, pl.quotient_cap);
         cb.zeta = ch.get_extension_challenge();                                                     // :206
         const int nz = s.n_cols + s.n_perm_z + s.n_quotient, nzn = s.n_cols + s.n_perm_z;
-        for (int i = 0; i < nz; i++) ch.observe_extension_element(proof_ext(zeta_word(i)));          // observe_openings (:208)
-        for (int i = 0; i < nzn; i++) ch.observe_extension_element(proof_ext(zeta_next_word(i)));
+        ch.observe_ext_words(nz, [&](int i) { return zeta_word(i); });                               // observe_openings (:208)
+        ch.observe_ext_words(nzn, [&](int i) { return zeta_next_word(i); });
         // get_fri_challenges (:128-165)
         cb.fri_alpha = ch.get_extension_challenge();
         for (int i = 0; i < d.n_steps; i++) { observe_cap(ch, pl.commit_caps + (uint64_t)i * d.cap_size * 4); cb.fri_betas[i] = ch.get_extension_challenge(); }
-        for (int i = 0; i < d.final_poly_len; i++) ch.observe_extension_element(proof_ext(pl.final_poly + 2ull * i));
+        ch.observe_ext_words(d.final_poly_len, [&](int i) { return pl.final_poly + 2ull * i; });
         ch.observe_element(be.proof_gl(pl.pow_witness));
         cb.fri_pow_response = ch.get_challenge();
         for (int i = 0; i < s.num_queries; i++) cb.fri_query_indices[i] = ch.get_challenge();

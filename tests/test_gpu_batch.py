@@ -123,8 +123,6 @@ def run_custom(h2w, h2w_api, oracle, consts, seeds, valid=False, **kw):
     ko, kh = consts
     sh, osh = _custom(h2w, oracle, **kw)
     plan = h2w_api.Plan(sh, kh)
-    if passes:
-        plan.configure(3, passes)          # H2W_OPT_CHAIN_PASSES
     n = len(seeds)
     proofs = [oracle.prove_fri(osh, ko, s) if valid else oracle.synth_proof(osh, s) for s in seeds]   # valid: oracle/prover.inc
     host = torch.empty(n * plan.proof_words, dtype=torch.int64)
