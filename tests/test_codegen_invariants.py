@@ -31,10 +31,10 @@ def _function(lines, mangled_prefix):
 
 
 def _loops(lines, lo, hi):
-    """(first, last) line of every natural loop = backward branch to a label inside [lo, hi)."""
+    """(first, last) line of every natural loop = backward branch (conditional or not) to a label inside [lo, hi)."""
     labels = {m.group(1): i for i in range(lo, hi) for m in [re.match(r"^(\.LBB\d+_\d+):", lines[i])] if m}
     for i in range(lo, hi):
-        m = re.search(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", lines[i])
+        m = re.search(r"^\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", lines[i])
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             yield labels[m.group(1)], i
 
@@ -43,22 +43,41 @@ def _count(lines, a, b, pat):
     return sum(1 for l in lines[a:b + 1] if re.match(r"^\s+" + pat, l))
 
 
+def _clean(lines, a, b, what):
+    bad = _count(lines, a, b, "scratch_") + _count(lines, a, b, "flat_")
+    assert bad == 0, f"{bad} scratch/flat accesses in the {what} (asm lines {a}-{b})"
+
+
 def test_chain_round_loops_have_no_scratch_or_flat_accesses(tmp_path):
     lines = _asm("batch.hip", tmp_path)
-    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi2EE13bn_emit_cells")       # the flat-layout emitter of k_merkle_bn_emit
+    # one-pass kernel (k_merkle_bn_fused): the emitter walks the S-box chain - five products (805 multiply-adds) per partial round
+    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi3EE13bn_emit_cellsILb0EE")
     loops = list(_loops(lines, lo, hi))
     partial = [(a, b) for a, b in loops if 780 <= _count(lines, a, b, "v_mad_u64_u32") <= 830]
     assert partial, "partial-round loop (five products, 805 multiply-adds) not found"
     a, b = min(partial, key=lambda ab: ab[1] - ab[0])
-    bad = _count(lines, a, b, "scratch_") + _count(lines, a, b, "flat_")
-    assert bad == 0, f"{bad} scratch/flat accesses in the partial-round loop (asm lines {a}-{b})"
+    _clean(lines, a, b, "one-pass partial-round loop")
     n = sum(1 for l in lines[a:b + 1] if re.match(r"^\s+[a-z]", l))
     assert n <= 2200, f"partial round grew to {n} instructions"
-    # the full-round loop: x^5 (five products) around the rolled four-product mix loop
     full = [(c, d) for c, d in loops if (d < a or c > b) and 700 <= _count(lines, c, d, "v_mad_u64_u32") <= 1100]
     assert full, "full-round loop not found"
     for c, d in full:
-        assert _count(lines, c, d, "scratch_") + _count(lines, c, d, "flat_") == 0, f"scratch/flat accesses in the full-round loop (asm lines {c}-{d})"
+        _clean(lines, c, d, "one-pass full-round loop")
+    # emission kernel of the two-pass paths (k_merkle_bn_emit): two products per partial round, rounds in pairs (644 multiply-adds per trip),
+    # the S-box values requested a pair ahead: no vector-memory wait but the two that admit the next pair's loads
+    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi2EE13bn_emit_cellsILb1EE")
+    loops = list(_loops(lines, lo, hi))
+    pair = [(a, b) for a, b in loops if 630 <= _count(lines, a, b, "v_mad_u64_u32") <= 660]
+    assert pair, "two-round loop (four products) not found"
+    a, b = min(pair, key=lambda ab: ab[1] - ab[0])
+    _clean(lines, a, b, "emission partial-round loop")
+    waits = [int(m.group(1)) for l in lines[a:b + 1] for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)] if m]
+    assert waits and min(waits) >= 30, f"a vector-memory wait in the emission loop drains the store queue: vmcnt {waits}"
+    # values kernel (k_merkle_bn_values): no scratch in its round loops either
+    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi1EE9bn_values")
+    for c, d in _loops(lines, lo, hi):
+        if _count(lines, c, d, "v_mad_u64_u32") >= 400:
+            _clean(lines, c, d, "values-pass round loop")
 
 
 def test_expand_fast_has_no_scratch(tmp_path):
