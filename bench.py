@@ -46,6 +46,7 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 OPT_FORK_CHAINS = 1     # include/h2w.h H2W_OPT_FORK_CHAINS
 OPT_SERIAL_EXPAND = 2   # include/h2w.h H2W_OPT_SERIAL_EXPAND
+OPT_CHAIN_PASSES = 3    # include/h2w.h H2W_OPT_CHAIN_PASSES
 
 
 def cpu_baseline(shape_args, hash_mode, lookup_bits, budget_s=12.0):
@@ -75,7 +76,7 @@ def cpu_baseline(shape_args, hash_mode, lookup_bits, budget_s=12.0):
             "proofs_per_s": n / busy, "_cells": cells, "_proofs": n, "_seconds": busy}
 
 
-def cpu_baseline_all_cores(shape_args, hash_mode, lookup_bits, cells_per_proof, budget_s=10.0):
+def cpu_baseline_all_cores(shape_args, hash_mode, lookup_bits, cells_per_proof, budget_s=8.0):
     """The same oracle loop in one process per host core this process may run on (one proof per core; the reference itself
     is single-threaded, so this is the most a user of it could get from the box).  Workers are fresh interpreters that never touch
     the GPU; their number is bounded by memory (a context holds its whole advice stream) and can be capped with H2W_CPU_WORKERS."""
@@ -88,17 +89,24 @@ def cpu_baseline_all_cores(shape_args, hash_mode, lookup_bits, cells_per_proof, 
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 32 << 30
-    cap = int(os.environ.get("H2W_CPU_WORKERS", "64"))
-    workers = max(1, min(ncores, cap, int(0.5 * avail // (cells_per_proof * 40))))
+    cap = int(os.environ.get("H2W_CPU_WORKERS", "0")) or ncores        # every core this process may run on, unless capped
+    most = max(1, min(ncores, cap, int(0.4 * avail // (cells_per_proof * 48))))      # a context holds its whole advice stream (32 B / cell + bookkeeping)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps([list(shape_args), hash_mode, lookup_bits, budget_s])]
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(workers)]
-    res = [json.loads(p.communicate(timeout=budget_s * 6 + 120)[0].strip().splitlines()[-1]) for p in procs]
-    wall = time.perf_counter() - t0
-    cells = sum(r["cells"] for r in res); n = sum(r["proofs"] for r in res); span = max(r["seconds"] for r in res)
-    return {"value": cells / span, "unit": "cells/s", "cores": workers, "host_cores_visible": ncores, "kind": "port",
-            "sample": f"{n} proof(s) of the same shape over {workers} single-threaded oracle processes ({span:.1f} s inside the gadget each, {wall:.1f} s wall incl. start-up)",
-            "proofs_per_s": n / span}
+
+    def run(workers):
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(workers)]
+        res = [json.loads(p.communicate(timeout=budget_s * 12 + 240)[0].strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t0
+        cells = sum(r["cells"] for r in res); n = sum(r["proofs"] for r in res); span = max(r["seconds"] for r in res)
+        return {"value": cells / span, "unit": "cells/s", "cores": workers, "host_cores_visible": ncores, "kind": "port",
+                "sample": f"{n} proof(s) of the same shape over {workers} single-threaded oracle processes ({span:.1f} s inside the gadget each, {wall:.1f} s wall incl. start-up)",
+                "proofs_per_s": n / span}
+    # every core, and a quarter of them: one context per process streams ~1 GB per proof, so the host's memory system, not its core count, sets the rate
+    runs = [run(w) for w in sorted({most, max(1, most // 4)})]
+    best = max(runs, key=lambda r: r["value"])
+    best["other_worker_counts"] = [{"cores": r["cores"], "value": r["value"], "proofs_per_s": r["proofs_per_s"]} for r in runs if r is not best]
+    return best
 
 
 def _cpu_worker(spec):
@@ -142,6 +150,8 @@ def main():
     ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--shard-queries", action="store_true", help="N > 1: shard the (proof, query) units of the SAME proofs over the ranks (strong scaling; default for cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the primary metric (one-proof latency, Goldilocks-caps secondary, eager boundary)")
+    ap.add_argument("--compact", action="store_true", help="--shard-queries: every rank writes a packed buffer of its own blocks (h2w_fri_witness_batch_shard_compact)")
     ap.add_argument("--no-fork", action="store_true", help="experiment: PoseidonBN254 chain kernels on the caller's stream (H2W_OPT_FORK_CHAINS = 0)")
     ap.add_argument("--serial-expand", type=int, default=-1, choices=[-1, 0, 1], help="H2W_OPT_SERIAL_EXPAND (-1: the library's default)")
     ap.add_argument("--chain-passes", type=int, default=0, choices=[0, 1, 2], help="H2W_OPT_CHAIN_PASSES (0: the library's default)")
@@ -184,7 +194,7 @@ def main():
     if args.serial_expand >= 0:
         plan.configure(OPT_SERIAL_EXPAND, args.serial_expand)
     if args.chain_passes:
-        plan.configure(3, args.chain_passes)
+        plan.configure(OPT_CHAIN_PASSES, args.chain_passes)
 
     cell_bytes = plan.num_cells * 32
     B = args.batch if args.batch > 0 else max(1, min(64, int(58.6e9 // cell_bytes)))
@@ -238,7 +248,8 @@ def main():
         assert hi - lo == B
         my_proofs = all_proofs[lo * words:hi * words]
 
-    advices = [torch.empty(B * cell_bytes, dtype=torch.uint8, device=dev) for _ in range(S)]
+    adv_bytes = plan.shard_cells(B, rank, world) * 32 if (shard_queries and args.compact) else B * cell_bytes
+    advices = [torch.empty(adv_bytes, dtype=torch.uint8, device=dev) for _ in range(S)]
     wss = [torch.empty(plan.workspace_bytes(B), dtype=torch.uint8, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     torch.cuda.synchronize()
@@ -248,7 +259,7 @@ def main():
         if i is None:
             i = counter[0] % S; counter[0] += 1
         if shard_queries:
-            plan.run_shard(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), rank, world, streams[i].cuda_stream)
+            (plan.run_shard_compact if args.compact else plan.run_shard)(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), rank, world, streams[i].cuda_stream)
         else:
             plan.run(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
 
@@ -278,11 +289,17 @@ def main():
 
     # per-kernel timing from the HIP events the library records on the streams it launches on
     # (a) over the timed region (launches overlap each other there, so these intervals include time-sharing);
-    keys = ("prologue_values", "perm_records", "glue_strands" if hash_mode == 1 else "glue_and_merkle_strands", "chain_values", "chain_emit", "expand", "launch")
-    NK = len(keys)
+    KEYS2 = ("prologue_values", "perm_records", "glue_strands" if hash_mode == 1 else "glue_and_merkle_strands", "chain_values", "chain_emit", "expand", "launch")
+    KEYS1 = KEYS2[:3] + ("merkle_chains", None, "expand", "launch")        # one pass: ms[3] is k_merkle_bn_fused, ms[4] nothing
+
+    def by_kernel(rows):
+        passes = int(rows[0][7]) if hash_mode == 1 else 0
+        keys = KEYS1 if passes == 1 else KEYS2
+        avg = [sum(t[k] for t in rows) / len(rows) for k in range(7)]
+        return {kk: avg[i] for i, kk in enumerate(keys) if kk and not (hash_mode == 0 and kk.startswith("chain_"))}, passes
+
     nback = min(args.steps * R, 64)
-    tim = [plan.timing_ex(i) for i in range(nback)]
-    overl = [sum(t[k] for t in tim) / nback for k in range(NK)]
+    overl, passes_timed = by_kernel([plan.timing_ex(i) for i in range(nback)])
     # how the expansion kernels of successive launches lie against each other (H2W_EV_EXPAND_START = 6, _END = 7): the gap from the
     # end of one to the start of the next (negative = they overlapped) and the spacing of their ends = the steady-state launch period
     ng = min(nback - 1, 24)
@@ -290,20 +307,28 @@ def main():
     period = [plan.event_gap(i + 1, 7, i, 7) for i in range(ng)]
     schedule = {"launches": ng, "expand_end_to_next_expand_start_ms": {"avg": sum(gaps) / ng, "min": min(gaps), "max": max(gaps)},
                 "expand_end_to_next_expand_end_ms": {"avg": sum(period) / ng, "min": min(period), "max": max(period)}} if ng > 0 else None
-    # (b) isolated: one launch at a time on one stream, the chain kernel on the same stream (no intra-launch overlap), so that every
-    #     kernel's event interval is its own duration
-    isol = None
-    if args.calib > 0:
+
+    # (b) isolated: one launch at a time on one stream, the chain kernels on the same stream (no intra-launch overlap), so that every
+    #     kernel's event interval is its own duration; with PoseidonBN254 caps in both forms of the Merkle paths (H2W_OPT_CHAIN_PASSES)
+    def isolated(passes=None):
         plan.configure(OPT_FORK_CHAINS, 0)
-        iso = []
+        if passes is not None:
+            plan.configure(OPT_CHAIN_PASSES, passes)
+        rows = []
         for _ in range(args.calib + 1):
             torch.cuda.synchronize()
             launch(0)
             torch.cuda.synchronize()
-            iso.append(plan.timing_ex(0))
-        iso = iso[1:]
-        isol = [sum(t[k] for t in iso) / len(iso) for k in range(NK)]
+            rows.append(plan.timing_ex(0))
         plan.configure(OPT_FORK_CHAINS, 0 if args.no_fork else 1)
+        plan.configure(OPT_CHAIN_PASSES, args.chain_passes)
+        return by_kernel(rows[1:])[0]
+
+    isol = isol_other = None
+    if args.calib > 0:
+        isol = isolated()
+        if hash_mode == 1:
+            isol_other = isolated(2 if passes_timed == 1 else 1)
     # (c) the expansion kernel with its launches back to back on the bench's streams (h2w_fri_expand_records: expansion only),
     #     three rounds over all streams; aggregate bytes / wall time
     b2b_gbs = None
@@ -316,6 +341,69 @@ def main():
                 plan.expand_records(B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
         torch.cuda.synchronize()
         b2b_gbs = rounds * S * B * plan.num_record_cells * 32 / (time.perf_counter() - tb) / 1e9
+    # (d) latency of ONE proof: a launch of a single proof, start to finish on an idle GPU (the library's default schedule), median of 10
+    def one_proof_ms(pl, proof_ptr, adv, ws):
+        st = streams[0].cuda_stream
+        ts = []
+        for _ in range(11):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pl.run(proof_ptr, 1, adv.data_ptr(), ws.data_ptr(), st)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        return sorted(ts[1:])[len(ts[1:]) // 2]
+
+    latency = None
+    if args.calib > 0 and world == 1 and not args.no_extras:
+        latency = {("%s_%s_batch1_ms" % (args.config, args.hash)): one_proof_ms(plan, my_proofs.data_ptr(), advices[0], wss[0]),
+                   "what": "wall time of one h2w_fri_witness_batch call on a single proof, enqueue to completion on an idle GPU (median of 10)"}
+    per_rank = None
+    if world > 1 and isol:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "kernel_ms_isolated": isol})
+        per_rank = gathered
+
+    # ---- secondary legs (N = 1): the same shape with Goldilocks-Poseidon caps; the level-1 (eager NativeChip) boundary
+    secondary = eager = None
+    if world == 1 and not args.no_extras and args.config == "cfg3" and hash_mode == 1:
+        for t in advices + wss:
+            del t
+        advices.clear(); wss.clear()
+        torch.cuda.empty_cache()
+        gshape = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=0, lookup_bits=args.lookup_bits)
+        gplan = api.Plan(gshape, consts, local_rank)
+        gB = max(1, int(58.6e9 // (gplan.num_cells * 32))); gS = 3
+        prng = np.random.default_rng(0xF1B00003)
+        gproofs = torch.from_numpy(prng.integers(0, 1 << 60, gB * gplan.proof_words, dtype=np.int64)).to(dev)
+        gadv = [torch.empty(gB * gplan.num_cells * 32, dtype=torch.uint8, device=dev) for _ in range(gS)]
+        gws = [torch.empty(gplan.workspace_bytes(gB), dtype=torch.uint8, device=dev) for _ in range(gS)]
+
+        def glaunches(n):
+            for j in range(n):
+                gplan.run(gproofs.data_ptr(), gB, gadv[j % gS].data_ptr(), gws[j % gS].data_ptr(), streams[j % gS].cuda_stream)
+        glaunches(2 * gS); torch.cuda.synchronize()
+        nl = 24
+        t1 = time.perf_counter(); glaunches(nl); torch.cuda.synchronize(); gt = time.perf_counter() - t1
+        secondary = {"workload": f"{args.config} with Goldilocks-Poseidon Merkle caps ({gplan.num_cells} cells = {gplan.num_cells * 32 / 1e9:.1f} GB per proof), uniform random proof words",
+                     "value": gplan.num_cells * gB * nl / gt, "unit": "cells/s", "proofs_per_launch": gB, "launches": nl, "launches_in_flight": gS, "seconds": gt,
+                     "frac_of_hbm_peak": gplan.num_cells * gB * nl * 32 / gt / 1e9 / HBM_PEAK_GBS}
+        if latency is not None:
+            latency[f"{args.config}_gl_batch1_ms"] = one_proof_ms(gplan, gproofs.data_ptr(), gadv[0], gws[0])
+        del gadv, gws
+        gplan.close(); torch.cuda.empty_cache()
+        # the literal drop-in of north_star: the verifier's chips drive NativeChip-level calls (field/native.rs:28-193), one per operation, values
+        # on the host; the cells are materialised on the GPU from the recorded block records when the advice is asked for
+        hp = my_proofs[:plan.proof_words].cpu().numpy().astype(np.uint64)
+        ctx = api.Context(args.lookup_bits, True, local_rank)
+        t1 = time.perf_counter()
+        api.verify_stark(ctx, shape, consts, hp)
+        t2 = time.perf_counter()
+        ptr = ctx.advice_device()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        eager = {"workload": f"{args.config}, PoseidonBN254 caps: h2w_chip_verify_stark = the gadget stack over nothing but the level-1 / level-2 C ABI (one call per NativeChip / GoldilocksChip operation)",
+                 "cells": ctx.num_cells(), "value": ctx.num_cells() / (t3 - t1), "unit": "cells/s", "host_seconds": t2 - t1, "expand_seconds": t3 - t2, "advice_on": "device" if ptr else None}
+        ctx.close()
 
     if rank == 0:
         launches = args.steps * R
@@ -325,20 +413,27 @@ def main():
         share = (1.0 / world) if shard_queries else 1.0      # a rank's share of the cells of a launch
         kbytes = {"expand": B * plan.num_record_cells * 32 * share}
         if hash_mode == 1:
-            kbytes["chain_emit"] = B * plan.num_chain_cells * 32 * share
+            kbytes["chain_emit"] = kbytes["merkle_chains"] = B * plan.num_chain_cells * 32 * share
         names = {"expand": "expand_fast<%d, true>" % args.lookup_bits if args.lookup_bits in (21, 13, 8) else "expand_kernel_t", "chain_emit": "k_merkle_bn_emit", "chain_values": "k_merkle_bn_values",
-                 "prologue_values": "k_prologue_values", "perm_records": "k_glp_emit", "glue_strands": "k_strands", "glue_and_merkle_strands": "k_strands + k_merkle_gl_values"}
-        kernels = {}
+                 "merkle_chains": "k_merkle_bn_fused", "prologue_values": "k_prologue_load + k_prologue_values", "perm_records": "k_glp_emit", "glue_strands": "k_strands",
+                 "glue_and_merkle_strands": "k_strands + k_merkle_gl_values"}
+
+        def table(iso, reg):
+            out_ = {}
+            for kk, ms in iso.items():
+                if kk == "launch":
+                    continue
+                ent = {"kernel": names.get(kk, kk), "ms_isolated": ms}
+                if reg is not None and kk in reg:
+                    ent["ms_timed_region"] = reg[kk]
+                if kk in kbytes:
+                    ent["algorithmic_bytes"] = kbytes[kk]; ent["achieved_GBps"] = kbytes[kk] / (ms * 1e-3) / 1e9; ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBS
+                out_[kk] = ent
+            return out_
+        kernels = table(isol, overl) if isol else {}
         dom, achieved = "expand", None
         if isol:
-            for i, kk in enumerate(keys[:NK - 1]):
-                if kk in ("chain_values", "chain_emit") and hash_mode == 0:
-                    continue
-                ent = {"kernel": names.get(kk, kk), "ms_isolated": isol[i], "ms_timed_region": overl[i]}
-                if kk in kbytes:
-                    ent["algorithmic_bytes"] = kbytes[kk]; ent["achieved_GBps"] = kbytes[kk] / (isol[i] * 1e-3) / 1e9; ent["frac"] = ent["achieved_GBps"] / HBM_PEAK_GBS
-                kernels[kk] = ent
-            dom = max(kbytes, key=lambda kk: kernels[kk]["ms_isolated"])
+            dom = max((kk for kk in kernels if kk in kbytes), key=lambda kk: kernels[kk]["ms_isolated"])
             achieved = kernels[dom]["achieved_GBps"]
         out = {
             "metric": "FRI-verifier witness cells/sec", "value": value, "unit": "cells/s",
@@ -349,28 +444,35 @@ def main():
                        "step": f"{R} launches of h2w_fri_witness_batch{'_shard' if shard_queries else ''} x {B} proofs, round-robin over {S} streams ({warm_steps} warm-up steps)",
                        "proofs_per_launch": B, "launches_per_step": R, "launches_in_flight": S, "proofs_per_gpu_per_step": B * R,
                        "cells_per_proof": plan.num_cells, "includes_witness_load_cells": True,
+                       "merkle_path_passes": passes_timed if hash_mode == 1 else None,
                        "proofs": "valid FRI instances of random polynomials, generated on the GPU by the ingest rank (h2w_prove_fri_batch)" if args.proofs == "valid" and args.backend != "gloo" else "uniform random words of the proof's shape",
-                       "parallelism": (f"(proof, query) units of the same {B} proofs dealt round-robin to {world} ranks, prologue blocks to rank proof mod {world}; one broadcast of the proofs, no data-path collective"
+                       "parallelism": (f"(proof, query) units of the same {B} proofs dealt round-robin to {world} ranks, prologue blocks to rank proof mod {world}; every rank launches only its own units "
+                                       f"({'packed per-rank advice buffers' if args.compact else 'blocks at their global offsets'}); one broadcast of the proofs, no data-path collective"
                                        if shard_queries else f"proof-sharded x{world}, one broadcast of the proofs, no data-path collective")},
             "proofs_per_s": total_cells / plan.num_cells / elapsed,
             "input_generation": ({"proofs": total_proofs, "seconds": round(gen_seconds, 3), "proofs_per_s": round(total_proofs / gen_seconds, 1), "where": "GPU of rank 0, outside the timed region"} if gen_seconds else None),
             "advice_GBps": value * 32 / 1e9,
-            "kernel_ms_isolated": dict(zip(keys, isol)) if isol else None,
-            "kernel_ms_timed_region": dict(zip(keys, overl)),
+            "kernel_ms_isolated": isol,
+            "kernel_ms_timed_region": overl,
+            "kernel_ms_isolated_per_rank": per_rank,
             "expand_schedule_timed_region": schedule,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS if achieved else None),
                          "traffic": None, "algorithmic_bytes": kbytes.get(dom), "kernel": names[dom], "kernels": kernels,
+                         "other_merkle_path_form": ({"merkle_path_passes": 2 if passes_timed == 1 else 1, "kernels": table(isol_other, None), "launch_ms_isolated": isol_other.get("launch")} if isol_other else None),
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS / world,
                          "expand_back_to_back_GBps": b2b_gbs, "expand_back_to_back_frac": (b2b_gbs / HBM_PEAK_GBS if b2b_gbs else None),
-                         "note": "kernel = the advice-writing kernel with the largest ISOLATED duration; achieved = its algorithmic bytes (32 B x the cells it writes per launch) / "
-                                 f"its duration, launched alone ({args.calib} launches after the timed region, one at a time, every kernel on one stream; HIP events recorded by the library "
-                                 "on that stream). whole_job_frac = value x 32 B / peak per GPU (all kernels, overlapped launches). traffic: PMC counters are not collected in this process "
-                                 "(rocprofv3 --pmc passes of the same command: profiles/)"},
+                         "note": "kernel = the advice-writing kernel with the largest ISOLATED duration among the kernels of the timed region; achieved = its algorithmic bytes (32 B x the cells it "
+                                 f"writes per launch) / its duration, launched alone ({args.calib} launches after the timed region, one at a time, every kernel on one stream; HIP events recorded by the "
+                                 "library on that stream). other_merkle_path_form: the same launch with the other setting of H2W_OPT_CHAIN_PASSES (not what the timed region ran). whole_job_frac = value x 32 B / "
+                                 "peak per GPU (all kernels, overlapped launches). traffic: PMC counters are not collected in this process (rocprofv3 --pmc passes of the same workload: profiles/r03_pmc_*)"},
+            "latency": latency, "secondary": secondary, "eager": eager,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU legs run at N = 1 only (rank 0's host)
             cb = cpu_baseline((d, q, rb), hash_mode, args.lookup_bits)
             out["cpu_baseline"] = {k: v for k, v in cb.items() if not k.startswith("_")}
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            if latency is not None:
+                latency["cpu_ms_per_proof"] = 1e3 / cb["proofs_per_s"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores((d, q, rb), hash_mode, args.lookup_bits, plan.num_cells)
         print(json.dumps(out))
     if world > 1:

@@ -75,12 +75,27 @@ class Context:
         _ck(self.L.h2w_ctx_const_equalities(self.p, cells, vals), "h2w_ctx_const_equalities")
         return [(int(cells[i]), int.from_bytes(bytes(vals[i]), "little")) for i in range(n)]
 
+    def advice_device(self):
+        """Expands the pending records on the GPU; device pointer to num_cells * 32 bytes owned by the context (h2w_ctx_advice_device)."""
+        ptr = C.c_void_p()
+        _ck(self.L.h2w_ctx_advice_device(self.p, C.byref(ptr)), "h2w_ctx_advice_device")
+        return ptr.value
+
     def advice_bytes(self, first=0, count=None):
         """Expands the pending records on the GPU and returns canonical-LE cells as bytes."""
         n = self.num_cells() if count is None else count
         buf = (Fr * max(n, 1))()
         _ck(self.L.h2w_ctx_download(self.p, first, n, buf), "h2w_ctx_download")
         return bytes(buf)[: n * 32]
+
+
+def verify_stark(ctx, shape, consts, proof_words):
+    """The reference's test flow over the eager boundary (stark/mod.rs:483-508: load_zero, WitnessChip::load_proof_with_pis, StarkChip::verify_proof):
+    the gadget stack driven through nothing but the level-1 / level-2 C ABI (h2w_chip_verify_stark).  proof_words: numpy uint64 / ctypes array."""
+    import numpy as np
+    if isinstance(proof_words, np.ndarray):
+        proof_words = np.ascontiguousarray(proof_words, dtype=np.uint64).ctypes.data_as(C.POINTER(C.c_uint64))
+    _ck(ctx.L.h2w_chip_verify_stark(ctx.p, C.byref(shape), C.byref(consts), proof_words), "h2w_chip_verify_stark")
 
 
 def _arr(items):
@@ -360,10 +375,11 @@ class Plan:
         return tuple(ms)
 
     def timing_ex(self, back=0):
-        """Per kernel, ms: (prologue values, permutation records, glue strands, chain values, chain emission, expansion, whole call)."""
+        """Per kernel, ms: (prologue values, permutation records, glue strands, chain values | one-pass chains, chain emission, expansion, whole
+        call) and the chain passes the call ran with."""
         ms = (C.c_float * 8)()
         _ck(self.L.h2w_plan_timing_ex(self.p, back, ms), "h2w_plan_timing_ex")
-        return tuple(float(x) for x in ms)[:7]
+        return tuple(float(x) for x in ms)
 
     def last_timing(self):
         ms = (C.c_float * 5)()

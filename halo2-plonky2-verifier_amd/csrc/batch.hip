@@ -256,7 +256,7 @@ struct h2w_plan {
     static constexpr int EV_RING = 64, N_EV = 13, N_SIDE = 16;
     // per call: 0 start, 9 prologue values done, 11 / 12 permutation-record kernel start / end, 1 prologue block complete, 7 / 2 glue (+ Goldilocks Merkle
     // strands) start / done, 8 / 3 expansion start / done, 4 / 10 / 5 chain kernels start / values done / end, 6 end of call
-    hipEvent_t evr[EV_RING][N_EV];
+    hipEvent_t evr[EV_RING][N_EV]; int passes_of[EV_RING] = {0};
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
     int chain_passes = 0;            // H2W_OPT_CHAIN_PASSES (0: by the size of the launch)
     int serial_expand = 1;           // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's
@@ -566,6 +566,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             const dim3 sgrid((nunits * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK, nkinds);
             // one pass or two (include/h2w.h H2W_OPT_CHAIN_PASSES): a launch whose paths do not fill the chip is bound by the depth of a path - split it
             const int passes = p->chain_passes ? p->chain_passes : (nunits <= 512 ? 2 : 1);
+            p->passes_of[p->n_batches % h2w_plan::EV_RING] = passes;
             if (nunits && passes == 1) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_fused<true>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_fused<false>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
             if (nunits && passes != 1) hipLaunchKernelGGL(k_merkle_bn_values, sgrid, dim3(QUAD_BLOCK), 0, cstream, A);
             H2W_HIP(hipEventRecord(ev[10], cstream));
@@ -923,7 +924,7 @@ int h2w_plan_timing_ex(h2w_plan *p, uint64_t back, float ms[8]) {
     H2W_HIP(hipEventElapsedTime(&ms[4], ev[10], ev[5]));   // k_merkle_bn_emit
     H2W_HIP(hipEventElapsedTime(&ms[5], ev[8], ev[3]));    // expansion kernel
     H2W_HIP(hipEventElapsedTime(&ms[6], ev[0], ev[6]));    // whole call
-    ms[7] = 0;
+    ms[7] = p->shape.hash_mode == 1 ? (float)p->passes_of[(p->n_batches - 1 - back) % h2w_plan::EV_RING] : 0.f;
     return 0;
 }
 int h2w_plan_last_timing(h2w_plan *p, float ms[5]) { return h2w_plan_timing(p, 0, ms); }

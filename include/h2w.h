@@ -318,7 +318,8 @@ int h2w_plan_configure(h2w_plan *, int option, int value);
  * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
 int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
 /* The same per kernel: ms[0] k_prologue_values, ms[1] k_glp_emit (records of the listed Goldilocks-Poseidon permutations), ms[2] k_strands
- * (+ k_merkle_gl_values), ms[3] k_merkle_bn_values, ms[4] k_merkle_bn_emit, ms[5] expansion kernel, ms[6] whole call, ms[7] = 0. */
+ * (+ k_merkle_gl_values), ms[3] k_merkle_bn_values (one pass: k_merkle_bn_fused), ms[4] k_merkle_bn_emit, ms[5] expansion kernel, ms[6] whole call,
+ * ms[7] = the H2W_OPT_CHAIN_PASSES the call ran with (PoseidonBN254 caps; else 0). */
 int h2w_plan_timing_ex(h2w_plan *, uint64_t back, float ms[8]);
 int h2w_plan_last_timing(h2w_plan *, float ms[5]);
 /* Elapsed ms from event `which_a` of the batch call `back_a` calls before the last one to event `which_b` of the call `back_b` before
