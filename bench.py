@@ -149,9 +149,12 @@ def main():
     ap.add_argument("--calib", type=int, default=3, help="isolated launches after the timed region (one at a time, chain kernel on the caller's stream) for the per-kernel roofline numbers")
     ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--shard-queries", action="store_true", help="N > 1: shard the (proof, query) units of the SAME proofs over the ranks (strong scaling; default for cfg5)")
+    ap.add_argument("--layout", default="flat", choices=["flat", "columns"], help="columns: every kernel writes the FlexGate column layout directly (h2w_fri_witness_batch_columns, SURVEY 8f row 1)")
+    ap.add_argument("--k", type=int, default=22, help="--layout columns: rows per column = 2^k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the primary metric (one-proof latency, Goldilocks-caps secondary, eager boundary)")
-    ap.add_argument("--compact", action="store_true", help="--shard-queries: every rank writes a packed buffer of its own blocks (h2w_fri_witness_batch_shard_compact)")
+    ap.add_argument("--compact", action="store_true", help="--shard-queries: every rank writes a packed buffer of its own blocks (h2w_fri_witness_batch_shard_compact; the default there)")
+    ap.add_argument("--flat-shards", action="store_true", help="--shard-queries: every rank keeps a full-size advice buffer and writes its blocks at their global offsets")
     ap.add_argument("--no-fork", action="store_true", help="experiment: PoseidonBN254 chain kernels on the caller's stream (H2W_OPT_FORK_CHAINS = 0)")
     ap.add_argument("--serial-expand", type=int, default=-1, choices=[-1, 0, 1], help="H2W_OPT_SERIAL_EXPAND (-1: the library's default)")
     ap.add_argument("--chain-passes", type=int, default=0, choices=[0, 1, 2], help="H2W_OPT_CHAIN_PASSES (0: the library's default)")
@@ -184,6 +187,8 @@ def main():
     d, q, rb, desc = CONFIGS[args.config]
     hash_mode = 1 if args.hash == "bn254" else 0
     shard_queries = (args.shard_queries or args.config == "cfg5") and world > 1
+    if shard_queries and not args.flat_shards:
+        args.compact = True          # a rank's buffers hold its own blocks only: 1 / world of the stream, so world x the launches fit in flight
     shape = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=hash_mode, lookup_bits=args.lookup_bits)
     # Poseidon constants: the published plonky2 / circomlib parameter sets the reference links in (h2w_poseidon_published;
     # pinned to published known-answer vectors in tests/test_poseidon_published.py).
@@ -197,13 +202,21 @@ def main():
         plan.configure(OPT_CHAIN_PASSES, args.chain_passes)
 
     cell_bytes = plan.num_cells * 32
+    bps = None
+    if args.layout == "columns":
+        assert not shard_queries, "--layout columns is a single-rank / proof-sharded mode"
+        bps = plan.break_points(args.k)
+        cell_bytes = ((len(bps) + 1) << args.k) * 32      # a proof's columns: (break points + 1) x 2^k cells
     B = args.batch if args.batch > 0 else max(1, min(64, int(58.6e9 // cell_bytes)))
     S = max(1, args.streams)
+    if shard_queries and args.compact:
+        S = min(S * min(world, 4), 16)      # a sharded launch is short (1 / world of the bytes behind the same serial strands): more of them in flight
     if args.share_gpu0:
         args.advice_cap_gb /= world
     free_b, _total_b = torch.cuda.mem_get_info(dev)         # leave 16 GB for the workspaces, the proofs and the allocator
     args.advice_cap_gb = min(args.advice_cap_gb, (free_b / (world if args.share_gpu0 else 1) - 16e9) / 1e9)
-    while S > 1 and S * B * cell_bytes > args.advice_cap_gb * 1e9:   # stay inside the 288 GB of HBM
+    per_launch = B * cell_bytes / (world if (shard_queries and args.compact) else 1)
+    while S > 1 and S * per_launch > args.advice_cap_gb * 1e9:   # stay inside the 288 GB of HBM
         S -= 1
     R = max(args.launches_per_step, 1)
     total_proofs = B if shard_queries else B * world      # distinct proofs resident per step (every launch of a rank re-uses its B proofs)
@@ -258,7 +271,9 @@ def main():
     def launch(i=None):
         if i is None:
             i = counter[0] % S; counter[0] += 1
-        if shard_queries:
+        if bps is not None:
+            plan.run_columns(my_proofs.data_ptr(), B, bps, args.k, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
+        elif shard_queries:
             (plan.run_shard_compact if args.compact else plan.run_shard)(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), rank, world, streams[i].cuda_stream)
         else:
             plan.run(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
@@ -332,7 +347,7 @@ def main():
     # (c) the expansion kernel with its launches back to back on the bench's streams (h2w_fri_expand_records: expansion only),
     #     three rounds over all streams; aggregate bytes / wall time
     b2b_gbs = None
-    if args.calib > 0 and not shard_queries:
+    if args.calib > 0 and not shard_queries and bps is None:
         torch.cuda.synchronize()
         tb = time.perf_counter()
         rounds = 3
@@ -354,7 +369,7 @@ def main():
         return sorted(ts[1:])[len(ts[1:]) // 2]
 
     latency = None
-    if args.calib > 0 and world == 1 and not args.no_extras:
+    if args.calib > 0 and world == 1 and not args.no_extras and bps is None:
         latency = {("%s_%s_batch1_ms" % (args.config, args.hash)): one_proof_ms(plan, my_proofs.data_ptr(), advices[0], wss[0]),
                    "what": "wall time of one h2w_fri_witness_batch call on a single proof, enqueue to completion on an idle GPU (median of 10)"}
     per_rank = None
@@ -365,7 +380,7 @@ def main():
 
     # ---- secondary legs (N = 1): the same shape with Goldilocks-Poseidon caps; the level-1 (eager NativeChip) boundary
     secondary = eager = None
-    if world == 1 and not args.no_extras and args.config == "cfg3" and hash_mode == 1:
+    if world == 1 and not args.no_extras and args.config == "cfg3" and hash_mode == 1 and bps is None:
         for t in advices + wss:
             del t
         advices.clear(); wss.clear()
@@ -444,6 +459,7 @@ def main():
                        "step": f"{R} launches of h2w_fri_witness_batch{'_shard' if shard_queries else ''} x {B} proofs, round-robin over {S} streams ({warm_steps} warm-up steps)",
                        "proofs_per_launch": B, "launches_per_step": R, "launches_in_flight": S, "proofs_per_gpu_per_step": B * R,
                        "cells_per_proof": plan.num_cells, "includes_witness_load_cells": True,
+                       "layout": ("flat advice stream" if bps is None else f"FlexGate columns written directly: {len(bps) + 1} columns of 2^{args.k} rows per proof (break points of halo2-base assign_with_constraints, 9 unusable rows)"),
                        "merkle_path_passes": passes_timed if hash_mode == 1 else None,
                        "proofs": "valid FRI instances of random polynomials, generated on the GPU by the ingest rank (h2w_prove_fri_batch)" if args.proofs == "valid" and args.backend != "gloo" else "uniform random words of the proof's shape",
                        "parallelism": (f"(proof, query) units of the same {B} proofs dealt round-robin to {world} ranks, prologue blocks to rank proof mod {world}; every rank launches only its own units "

@@ -269,13 +269,21 @@ __device__ __forceinline__ bool fast_tile_range(const ExpandArgs &A, uint64_t pr
     }
     return true;
 }
-template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
+constexpr int FAST_MAX_COLS = 64;                           // column-major emission through the fast kernel: the column table lives in LDS
+template <int L, bool ROAM, bool COLS> __global__ __launch_bounds__(EXPAND_THREADS, 2) void expand_fast(ExpandArgs A) {
     typedef FastMap<L> M;
     constexpr int NCH = (M::VT + FAST_CH - 1) / FAST_CH;
     constexpr int ROW = M::VT * 16 + 16;                      // bytes per record row of the LDS tile: the low halves of its virtual cells (+ padding); the last step's lanes past VT never read
     constexpr int TILE = (FAST_T + 1) * ROW;                  // + one row of HIGH halves: zeros, and the high half of -2^RB at its two cells (what the odd pieces store)
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[EXPAND_THREADS / 64][TILE];
     __shared__ uint2 s_vbr[EXPAND_THREADS / 64][FAST_T];     // per record: {flat index of its virtual cell 0, vs | ve << 8}
+    // column-major emission: cell i of the flat stream lives at i + delta(column of i), a piecewise-constant shift.  A record's cells
+    // are contiguous and cross at most one column boundary: per record the shift of its first cell, the flat index where the next column starts
+    // (none: 2^32 - 1) and the change of the shift there.  The column starts are staged in LDS: a vector load here would wait for every cell store
+    // the wavefront has in flight.
+    __shared__ ull s_cstart[COLS ? FAST_MAX_COLS : 1];
+    __shared__ ull s_cd0[EXPAND_THREADS / 64][COLS ? FAST_T : 1], s_cdd[EXPAND_THREADS / 64][COLS ? FAST_T : 1]; __shared__ uint32_t s_csplit[EXPAND_THREADS / 64][COLS ? FAST_T : 1];
+    if constexpr (COLS) { for (uint32_t i = threadIdx.x; i < A.cm.ncols; i += EXPAND_THREADS) s_cstart[i] = A.cm.starts[i]; __syncthreads(); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // which proof: one column of the grid per proof (static), or - roam - a grid of as many blocks as the chip holds at once, whose wavefronts
     // start spread over the proofs and move on to the next proof that has tiles left.  With more blocks than fit, the late ones start when
@@ -362,6 +370,14 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
                     b.Wlo = (ull)W; b.Whi = (ull)(W >> 64);
                 }
                 s_vbr[wv][lane] = make_uint2((uint32_t)coff - (uint32_t)vs, (uint32_t)vs | ((uint32_t)ve << 8));      // (index mod 2^32: a proof's stream is shorter)
+                if constexpr (COLS) {
+                    uint32_t a = 0, b = A.cm.ncols;                // largest c with starts[c] <= coff
+                    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (s_cstart[mid] <= coff) a = mid; else b = mid; }
+                    const ull d0 = ((ull)a << A.cm.k) - s_cstart[a], ncell = slow ? (t == T_CONST4 ? 4 : 12) : (ull)(ve - vs);
+                    const bool cross = a + 1 < A.cm.ncols && coff + ncell > s_cstart[a + 1];
+                    s_cd0[wv][lane] = d0; s_csplit[wv][lane] = cross ? (uint32_t)s_cstart[a + 1] : 0xffffffffu;
+                    s_cdd[wv][lane] = cross ? ((ull)(a + 1) << A.cm.k) - s_cstart[a + 1] - d0 : 0;
+                }
 #pragma clang loop unroll(full)
                 for (int c = 0; c < NCH; c++) {
 #pragma clang loop unroll(full)
@@ -383,8 +399,19 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
                 const unsigned char *rd = hi ? hi_base : rd_base + g * 4 * ROW;                   // low halves from the record's row, high halves from the template row
                 // (br.x = cell index of virtual cell 0, mod 2^32: negative when the stream starts inside the record's virtual list, e.g. a LOADW
                 //  block at cell 0; the steps that are stored, c >= c_lo, land at or after the record's first real cell)
-                unsigned char *const dst = out_half + ((long long)(uint32_t)(br.x + (uint32_t)kc + 16u) - 16) * 32;       // (>= -8; streams of up to 2^32 - 32 cells) + 256 c per step: an immediate offset
-                if (__all(c_lo <= 1 && c_hi >= NCH - 2)) {       // four whole Goldilocks-op blocks (the usual case): only the first and the last step are ragged
+                long long first = (long long)(uint32_t)(br.x + (uint32_t)kc + 16u) - 16;      // flat index of this lane's cell of step 0 (>= -8; streams of up to 2^32 - 32 cells)
+                uint32_t split = 0xffffffffu; ull dd = 0;
+                if constexpr (COLS) { const int ri = g * 4 + (lane >> 4); first += (long long)s_cd0[wv][ri]; split = s_csplit[wv][ri]; dd = s_cdd[wv][ri]; }
+                unsigned char *const dst = out_half + first * 32;       // + 256 c per step: an immediate offset
+                if (COLS && __any(split != 0xffffffffu)) {          // a record of the group runs into the next column (once per column and proof): per-cell shifts
+                    const long long flat0 = (long long)(uint32_t)(br.x + (uint32_t)kc + 16u) - 16;
+#pragma unroll 1
+                    for (int c = 0; c < NCH; c++)
+                        if (c >= c_lo && c <= c_hi) {
+                            const bool over = split != 0xffffffffu && flat0 + 8 * c >= (long long)split;
+                            *reinterpret_cast<u128s *>(dst + c * FAST_CH * 32 + (over ? (long long)dd * 32 : 0)) = *reinterpret_cast<const u128s *>(rd + c * FAST_CH * 16);
+                        }
+                } else if (__all(c_lo <= 1 && c_hi >= NCH - 2)) {       // four whole Goldilocks-op blocks (the usual case): only the first and the last step are ragged
                     if (c_lo <= 0) *reinterpret_cast<u128s *>(dst) = *reinterpret_cast<const u128s *>(rd);
 #pragma unroll
                     for (int c = 1; c < NCH - 1; c++) *reinterpret_cast<u128s *>(dst + c * FAST_CH * 32) = *reinterpret_cast<const u128s *>(rd + c * FAST_CH * 16);
@@ -397,9 +424,11 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
             }
             if (__any(slow)) {
                 if (slow) {
-                    u128s *d = reinterpret_cast<u128s *>(outb + coff * 32); const u128s z{0, 0};
-                    if (t == T_CONST4) { d[0] = u128s{rc.a, 0}; d[1] = z; d[2] = u128s{rc.b, 0}; d[3] = z; d[4] = u128s{rc.c, 0}; d[5] = z; d[6] = u128s{rc.d, 0}; d[7] = z; }
-                    else { for (int i = 0; i < 12; i++) { d[2 * i] = u128s{rc.a, 0}; d[2 * i + 1] = z; } }
+                    const u128s z{0, 0}; ull d0 = 0, dd = 0; uint32_t split = 0xffffffffu;
+                    if constexpr (COLS) { d0 = s_cd0[wv][lane]; dd = s_cdd[wv][lane]; split = s_csplit[wv][lane]; }
+                    auto at = [&](int i) { return reinterpret_cast<u128s *>(outb + (coff + (ull)i + d0 + ((COLS && coff + (ull)i >= split) ? dd : 0)) * 32); };
+                    if (t == T_CONST4) { const ull w4[4] = {rc.a, rc.b, rc.c, rc.d}; for (int i = 0; i < 4; i++) { u128s *d = at(i); d[0] = u128s{w4[i], 0}; d[1] = z; } }
+                    else { for (int i = 0; i < 12; i++) { u128s *d = at(i); d[0] = u128s{rc.a, 0}; d[1] = z; } }
                 }
             }
         }
@@ -423,7 +452,7 @@ template <int L, bool ROAM> __global__ __launch_bounds__(EXPAND_THREADS, 2) void
 // features), so the fast kernel serves the batched path whenever it is instantiated for the plan's lookup_bits
 int launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t stream) {
     if (A.nrec == 0 || nproofs == 0) return 0;
-    const bool fast_ok = A.tile_ctr != nullptr && A.pool == nullptr && A.cm.starts == nullptr && A.ntmpl <= T_DYNAMIC;
+    const bool fast_ok = A.tile_ctr != nullptr && A.pool == nullptr && (A.cm.starts == nullptr || (A.cm.ncols <= (uint32_t)FAST_MAX_COLS && A.shard_world <= 1)) && A.ntmpl <= T_DYNAMIC;
     if (fast_ok && (A.lookup_bits == 21 || A.lookup_bits == 13 || A.lookup_bits == 8)) {
         ExpandArgs B = A; B.nproofs = (uint32_t)nproofs; B.roam = 0;
         // work units per proof: all of its records, or - sharded - the prologue block plus ceil(nq / world) query blocks (an upper bound per proof)
@@ -450,15 +479,13 @@ int launch_expand(const ExpandArgs &A, uint64_t nproofs, int grid_x, hipStream_t
             if (nb < 1) nb = 1;
             B.roam = 1; grid = dim3((unsigned)nb, 1);
         }
-        if (B.roam) {
-            if (A.lookup_bits == 21) hipLaunchKernelGGL((expand_fast<21, true>), grid, dim3(EXPAND_THREADS), 0, stream, B);
-            else if (A.lookup_bits == 13) hipLaunchKernelGGL((expand_fast<13, true>), grid, dim3(EXPAND_THREADS), 0, stream, B);
-            else hipLaunchKernelGGL((expand_fast<8, true>), grid, dim3(EXPAND_THREADS), 0, stream, B);
-        } else {
-            if (A.lookup_bits == 21) hipLaunchKernelGGL((expand_fast<21, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
-            else if (A.lookup_bits == 13) hipLaunchKernelGGL((expand_fast<13, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
-            else hipLaunchKernelGGL((expand_fast<8, false>), grid, dim3(EXPAND_THREADS), 0, stream, B);
-        }
+        const bool cols = A.cm.starts != nullptr;
+#define H2W_LAUNCH_FAST(LB, RM, CL) hipLaunchKernelGGL((expand_fast<LB, RM, CL>), grid, dim3(EXPAND_THREADS), 0, stream, B)
+#define H2W_LAUNCH_FAST_L(LB) do { if (B.roam) { if (cols) H2W_LAUNCH_FAST(LB, true, true); else H2W_LAUNCH_FAST(LB, true, false); } \
+                                   else { if (cols) H2W_LAUNCH_FAST(LB, false, true); else H2W_LAUNCH_FAST(LB, false, false); } } while (0)
+        if (A.lookup_bits == 21) H2W_LAUNCH_FAST_L(21); else if (A.lookup_bits == 13) H2W_LAUNCH_FAST_L(13); else H2W_LAUNCH_FAST_L(8);
+#undef H2W_LAUNCH_FAST_L
+#undef H2W_LAUNCH_FAST
         return 0;
     }
     if (A.shard_compact) { set_error("expansion: the packed shard layout needs the fast expansion kernel (flat layout, lookup_bits 21 / 13 / 8)"); return -1; }

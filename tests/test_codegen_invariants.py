@@ -82,7 +82,7 @@ def test_chain_round_loops_have_no_scratch_or_flat_accesses(tmp_path):
 
 def test_expand_fast_has_no_scratch(tmp_path):
     lines = _asm("expand.hip", tmp_path)
-    for variant in ("_ZN3h2w11expand_fastILi21ELb0EE", "_ZN3h2w11expand_fastILi21ELb1EE"):      # static grid / roaming wavefronts
+    for variant in ("_ZN3h2w11expand_fastILi21ELb0ELb0EE", "_ZN3h2w11expand_fastILi21ELb1ELb0EE", "_ZN3h2w11expand_fastILi21ELb1ELb1EE"):      # static grid / roaming wavefronts
         lo, hi = _function(lines, variant)
         assert _count(lines, lo, hi, "scratch_") == 0
         assert _count(lines, lo, hi, "flat_store") == 0      # every cell store is a global_store
