@@ -29,6 +29,7 @@ struct octx {
     char **names; int nnames, capnames;
     char err[256]; int failed;
     int semantic; /* >0: constraints registered now are protocol checks on the (possibly invalid) proof */
+    uint64_t watch; int has_watch; char watch_path[2048]; uint64_t watch_enter; /* orc_watch_cell: the #[count] call stack that pushes one given cell */
 };
 
 enum { QC_EXISTING = 0, QC_WITNESS = 1, QC_CONSTANT = 2 };
@@ -98,6 +99,11 @@ static size_t scope_path(const octx_t *c, int node, char *buf, size_t cap) {
     size_t k = scope_path(c, c->nodes[node].parent, buf, cap);
     return k + (size_t)snprintf(buf + (k < cap ? k : cap), k < cap ? cap - k : 0, ";%s", c->names[c->nodes[node].name]);
 }
+/* Before a run on a context with track_scopes: remember which #[count] call stack appends cell `cell` (tools/compare_advice.py: names the
+ * chip function - and so the halo2-base template - in which two advice streams first differ).  orc_watch_path: that stack ("all;verify_proof;...")
+ * and the offset of the cell inside the innermost call's block. */
+void orc_watch_cell(octx_t *c, uint64_t cell) { c->watch = cell; c->has_watch = 1; c->watch_path[0] = 0; }
+const char *orc_watch_path(const octx_t *c, uint64_t *offset_in_call) { if (offset_in_call) *offset_in_call = c->watch - c->watch_enter; return c->watch_path; }
 size_t orc_scope_dump(const octx_t *c, char *buf, size_t cap) {
     size_t used = 0; char tmp[2048];
     if (!c->track) return 0;
@@ -110,7 +116,9 @@ size_t orc_scope_dump(const octx_t *c, char *buf, size_t cap) {
     return used;
 }
 
+static size_t scope_path(const octx_t *c, int node, char *buf, size_t cap);
 static inline void adv_push(octx_t *c, const ofr_t *v) {
+    if (c->has_watch && c->n == c->watch && c->track) { scope_path(c, c->cur, c->watch_path, sizeof(c->watch_path)); c->watch_enter = c->depth ? c->enter[c->depth - 1] : 0; }
     if (c->n == c->cap) { c->cap *= 2; c->advice = (ofr_t *)realloc(c->advice, c->cap * sizeof(ofr_t)); if (!c->advice) { fprintf(stderr, "oracle: OOM\n"); abort(); } }
     c->advice[c->n++] = *v;
 }

@@ -80,6 +80,9 @@ const char *orc_error(const octx_t *);
 int orc_mock_prover(const octx_t *, uint64_t *gates, uint64_t *equalities, uint64_t *lookups, uint64_t *semantic_failed);
 /* scope tree dump: writes "path cells\n" lines (inclusive counts) into buf; returns bytes needed */
 size_t orc_scope_dump(const octx_t *, char *buf, size_t cap);
+/* which #[count] call stack appends a given cell (set before the run; the context must track scopes) */
+void orc_watch_cell(octx_t *, uint64_t cell);
+const char *orc_watch_path(const octx_t *, uint64_t *offset_in_call);
 
 /* --- keygen metadata + FlexGate column layout (needs witness_gen_only = 0); halo2-lib semantics [R], see oracle.c --- */
 uint64_t orc_num_gates(const octx_t *);

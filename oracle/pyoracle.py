@@ -93,6 +93,9 @@ def lib():
     L.orc_mock_prover.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.orc_scope_dump.restype = C.c_size_t
     L.orc_scope_dump.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.orc_watch_cell.argtypes = [vp, C.c_uint64]
+    L.orc_watch_path.restype = C.c_char_p
+    L.orc_watch_path.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.orc_synth_consts.argtypes = [C.POINTER(Consts), C.c_uint64]
     L.orc_proof_words.restype = C.c_size_t
     L.orc_proof_words.argtypes = [C.POINTER(Shape)]
@@ -194,6 +197,14 @@ class Ctx:
 
     def error(self):
         return self.L.orc_error(self.p).decode()
+
+    def watch_cell(self, cell):
+        """Before a run (track_scopes=True): remember the #[count] call stack that appends `cell`."""
+        self.L.orc_watch_cell(self.p, cell)
+
+    def watch_path(self):
+        off = C.c_uint64()
+        return self.L.orc_watch_path(self.p, C.byref(off)).decode(), int(off.value)
 
     def scopes(self):
         n = self.L.orc_scope_dump(self.p, None, 0)
