@@ -29,6 +29,7 @@ struct octx {
     char **names; int nnames, capnames;
     char err[256]; int failed;
     int semantic; /* >0: constraints registered now are protocol checks on the (possibly invalid) proof */
+    int streaming; uint64_t digest[4]; /* orc_ctx_new_streaming: only the last ORC_RING cells are kept, the stream is summed into h2w_advice_digest's checksum */
     uint64_t watch; int has_watch; char watch_path[2048]; uint64_t watch_enter; /* orc_watch_cell: the #[count] call stack that pushes one given cell */
 };
 
@@ -55,6 +56,16 @@ octx_t *orc_ctx_new(int lookup_bits, int witness_gen_only, int track_scopes) {
     }
     return c;
 }
+/* A context for streams too long for the host (cfg 3 / cfg 5 with Goldilocks-Poseidon caps: 14 / 43 GB): the cells go into a ring of the last
+ * ORC_RING (every read-back of the templates is a few dozen cells deep: ctx_get) and into the position-dependent checksum that
+ * include/h2w.h's h2w_advice_digest computes on the device: digest[j] = sum_i limb_j(cell i) * ((((i + 1) * 0x9E3779B97F4A7C15) | 1) + 2 j) mod 2^64. */
+#define ORC_RING ((size_t)1 << 16)
+octx_t *orc_ctx_new_streaming(int lookup_bits) {
+    octx_t *c = orc_ctx_new(lookup_bits, 1, 0);
+    c->streaming = 1; c->cap = ORC_RING; c->advice = (ofr_t *)realloc(c->advice, c->cap * sizeof(ofr_t));
+    return c;
+}
+void orc_digest(const octx_t *c, uint64_t out[4]) { for (int j = 0; j < 4; j++) out[j] = c->digest[j]; }
 void orc_ctx_free(octx_t *c) {
     if (!c) return;
     free(c->advice); free(c->selector); free(c->eq); free(c->ceq); free(c->lookup);
@@ -62,7 +73,7 @@ void orc_ctx_free(octx_t *c) {
     for (int i = 0; i < c->nnames; i++) free(c->names[i]);
     free(c->names); free(c);
 }
-void orc_ctx_reserve(octx_t *c, uint64_t ncells) { if (ncells > c->cap) { c->cap = ncells; c->advice = (ofr_t *)realloc(c->advice, c->cap * sizeof(ofr_t)); if (!c->advice) { fprintf(stderr, "oracle: OOM\n"); abort(); } } }
+void orc_ctx_reserve(octx_t *c, uint64_t ncells) { if (!c->streaming && ncells > c->cap) { c->cap = ncells; c->advice = (ofr_t *)realloc(c->advice, c->cap * sizeof(ofr_t)); if (!c->advice) { fprintf(stderr, "oracle: OOM\n"); abort(); } } }
 uint64_t orc_num_cells(const octx_t *c) { return c->n; } /* util/context_wrapper.rs:24-26 */
 const ofr_t *orc_advice(const octx_t *c) { return c->advice; }
 const char *orc_error(const octx_t *c) { return c->failed ? c->err : ""; }
@@ -119,6 +130,12 @@ size_t orc_scope_dump(const octx_t *c, char *buf, size_t cap) {
 static size_t scope_path(const octx_t *c, int node, char *buf, size_t cap);
 static inline void adv_push(octx_t *c, const ofr_t *v) {
     if (c->has_watch && c->n == c->watch && c->track) { scope_path(c, c->cur, c->watch_path, sizeof(c->watch_path)); c->watch_enter = c->depth ? c->enter[c->depth - 1] : 0; }
+    if (c->streaming) {
+        const uint64_t m = (((uint64_t)c->n + 1) * 0x9E3779B97F4A7C15ULL) | 1ULL;
+        for (int j = 0; j < 4; j++) c->digest[j] += v->l[j] * (m + 2 * (uint64_t)j);
+        c->advice[c->n++ & (ORC_RING - 1)] = *v;
+        return;
+    }
     if (c->n == c->cap) { c->cap *= 2; c->advice = (ofr_t *)realloc(c->advice, c->cap * sizeof(ofr_t)); if (!c->advice) { fprintf(stderr, "oracle: OOM\n"); abort(); } }
     c->advice[c->n++] = *v;
 }
@@ -153,7 +170,9 @@ static void assign_region(octx_t *c, const qc_t *cells, int n, const int *gates,
     for (int g = 0; g < ng; g++) set_selector(c, row0 + (size_t)gates[g]);
 }
 static inline oav_t ctx_get(const octx_t *c, int64_t off) { /* Context::get: negative = from end */
-    oav_t a; a.cell = off < 0 ? (int64_t)c->n + off : off; a.v = c->advice[a.cell]; return a;
+    oav_t a; a.cell = off < 0 ? (int64_t)c->n + off : off;
+    if (c->streaming) { if ((size_t)a.cell >= c->n || c->n - (size_t)a.cell > ORC_RING) { fprintf(stderr, "oracle: streaming context read back beyond its ring\n"); abort(); } a.v = c->advice[(size_t)a.cell & (ORC_RING - 1)]; return a; }
+    a.v = c->advice[a.cell]; return a;
 }
 static inline oav_t ctx_last(const octx_t *c) { return ctx_get(c, -1); }
 
@@ -184,7 +203,7 @@ int orc_mock_prover(const octx_t *c, uint64_t *gates, uint64_t *equalities, uint
 static oav_t h2_load_witness(octx_t *c, const ofr_t *v) { qc_t q = Q_W(*v); assign_region(c, &q, 1, NULL, 0); return ctx_last(c); }
 static oav_t h2_load_constant(octx_t *c, const ofr_t *v) { qc_t q = Q_C(*v); assign_region(c, &q, 1, NULL, 0); return ctx_last(c); }
 static oav_t h2_load_zero(octx_t *c) { /* cached after first use [C] */
-    if (c->zero_cell >= 0) return ctx_get(c, c->zero_cell);
+    if (c->zero_cell >= 0) { oav_t a; a.cell = c->zero_cell; a.v = fr_from_u64(0); return a; }      /* (the cached cell holds 0: no read-back, the streaming context may have dropped it) */
     ofr_t z = fr_from_u64(0); oav_t a = h2_load_constant(c, &z); c->zero_cell = a.cell; return a;
 }
 static void h2_constrain_equal(octx_t *c, oav_t a, oav_t b, int kind) { add_eq(c, a.cell, b.cell, kind); }

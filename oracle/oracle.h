@@ -69,6 +69,9 @@ typedef struct octx octx_t;
 
 /* --- context --- */
 octx_t *orc_ctx_new(int lookup_bits, int witness_gen_only, int track_scopes);
+/* streams too long for the host: a ring of the last cells + the checksum of include/h2w.h's h2w_advice_digest (orc_advice is then meaningless) */
+octx_t *orc_ctx_new_streaming(int lookup_bits);
+void orc_digest(const octx_t *, uint64_t out[4]);
 void    orc_ctx_free(octx_t *);
 uint64_t orc_num_cells(const octx_t *);
 void orc_ctx_reserve(octx_t *, uint64_t ncells);   /* capacity hint (avoids realloc copies) */

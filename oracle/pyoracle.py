@@ -82,6 +82,9 @@ def lib():
     L.orc_ctx_new.restype = vp
     L.orc_ctx_new.argtypes = [C.c_int, C.c_int, C.c_int]
     L.orc_ctx_free.argtypes = [vp]
+    L.orc_ctx_new_streaming.restype = vp
+    L.orc_ctx_new_streaming.argtypes = [C.c_int]
+    L.orc_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.orc_ctx_reserve.argtypes = [vp, C.c_uint64]
     L.orc_num_cells.restype = C.c_uint64
     L.orc_num_cells.argtypes = [vp]
@@ -164,9 +167,15 @@ def lib():
 class Ctx:
     """An oracle context (halo2-base Context restated)."""
 
-    def __init__(self, lookup_bits=21, witness_gen_only=True, track_scopes=False):
+    def __init__(self, lookup_bits=21, witness_gen_only=True, track_scopes=False, streaming=False):
         self.L = lib()
-        self.p = self.L.orc_ctx_new(lookup_bits, 1 if witness_gen_only else 0, 1 if track_scopes else 0)
+        # streaming: for streams too long for the host - only a ring of the last cells is kept, the stream is summed into the checksum of h2w_advice_digest
+        self.p = self.L.orc_ctx_new_streaming(lookup_bits) if streaming else self.L.orc_ctx_new(lookup_bits, 1 if witness_gen_only else 0, 1 if track_scopes else 0)
+
+    def digest(self):
+        out = (C.c_uint64 * 4)()
+        self.L.orc_digest(self.p, out)
+        return [int(x) for x in out]
 
     def close(self):
         if self.p:

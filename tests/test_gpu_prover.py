@@ -278,6 +278,37 @@ def test_streamed_goldilocks_caps_digest(h2w, h2w_api, oracle, published):
     ctx.close(); pr.close(); plan.close()
 
 
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg5"])
+def test_full_size_goldilocks_caps_digest(h2w, h2w_api, oracle, published, cfg):
+    """The largest single streams of BASELINE.json with Goldilocks-Poseidon Merkle caps - configs[2]: 450 M cells = 14.4 GB, configs[4]'s shape: 1.33 G cells
+    = 42.6 GB per proof - against the oracle without a host copy: the device's h2w_advice_digest equals the checksum the oracle's streaming context
+    (a ring of the last cells + the same position-dependent sum) accumulates over its stream of the same proof; gates and lookups hold on the device."""
+    import torch
+    ko, kh = published
+    q = 28 if cfg == "cfg3" else 84
+    sh = h2w.fibonacci_shape(20, q, rate_bits=1, hash_mode=0); osh = oracle.fibonacci_shape(20, q, rate_bits=1, hash_mode=0)
+    plan = h2w_api.Plan(sh, kh)
+    st = torch.cuda.current_stream().cuda_stream
+    proof = oracle.synth_proof(osh, 0xF1B00003 if cfg == "cfg3" else 0xF1B00005)
+    d_proof = torch.frombuffer(bytearray(bytes(proof)), dtype=torch.int64).cuda()
+    advice = torch.empty(plan.num_cells * 32, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(1), dtype=torch.uint8, device="cuda")
+    digest = torch.zeros(4, dtype=torch.int64, device="cuda")
+    plan.run(d_proof.data_ptr(), 1, advice.data_ptr(), ws.data_ptr(), st)
+    plan.advice_digest(advice.data_ptr(), plan.num_cells, digest.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert plan.status(ws.data_ptr(), 1) == [0]
+    bad_gates, bad_lookups = plan.check_constraints(advice.data_ptr(), 1)
+    assert bad_gates == 0 and bad_lookups <= 4                     # (a random proof fails only the limbs of its PoW response)
+    got = [int(x) & 0xFFFFFFFFFFFFFFFF for x in digest.cpu().tolist()]
+    del advice; torch.cuda.empty_cache()
+    ctx = oracle.Ctx(21, streaming=True)
+    assert oracle.verify_stark(ctx, osh, ko, proof) == 0
+    assert ctx.num_cells() == plan.num_cells
+    assert got == ctx.digest()
+    ctx.close(); plan.close()
+
+
 def test_config5_valid_proof(h2w, h2w_api, oracle, published):
     """BASELINE.json configs[4]: 2^20 rows, 84 queries, PoseidonBN254 caps of height 4: a GPU-generated valid instance, its
     59.7 M + load cells checked gate by gate on the device and compared with the oracle's stream."""
