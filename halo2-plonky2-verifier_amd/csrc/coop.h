@@ -372,7 +372,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
 //   * every VALUE of a layer is written to LDS once (a "value slot", 32 B per quad and slot), not once per cell that shows it:
 //     the cells of a layer are a static list of sources (value slot | table entry), and the quad streams them out with all
 //     four lanes writing adjacent 16-byte pieces (64 contiguous bytes per quad and store instruction: the form that streams
-//     at the HBM ceiling, tools/ubench_store2.hip).  A partial round stages 7 values instead of 52 cells;
+//     at the HBM ceiling, tools/ubench/ubench_store3.hip).  A partial round stages 7 values instead of 52 cells;
 //   * quad-local exchanges are DPP moves (quad_perm), not ds_bpermute: no LDS round trip on the dependent chain;
 //   * one wavefront's LDS accesses execute in order, so no barrier or wait separates staging, flushing and re-staging.
 // Arithmetic is "hybrid": canonical state, const * var = ONE Montgomery product with the R-premultiplied constant, x^5 in five
@@ -562,7 +562,7 @@ template <bool COLS, int MODE> struct QuadSinkT {
     // The partial-round layer as a WAVEFRONT-wide stream: the quad-wise flush above writes 64 contiguous bytes per quad and store instruction,
     // i.e. sixteen 64-byte segments in sixteen different permutations per wavefront instruction - with every level of every path in flight that is
     // ~32 k interleaved write streams and the kernel sat at 3.7 TB/s with its arithmetic at 45 % (profiles/r03_emit_store_bound.txt).  Here the 64 lanes
-    // write 1 KB of ONE quad's layer per instruction (the form that streams at the ceiling, tools/ubench_store*.hip), quad after quad: lane j owns the
+    // write 1 KB of ONE quad's layer per instruction (the form that streams at the ceiling, tools/ubench/ubench_store*.hip), quad after quad: lane j owns the
     // 16-byte pieces j and 64 + j of every quad's 104-piece layer; where a piece comes from (value slot of that quad | table entry) is a per-lane
     // constant, worked out once per permutation.
     typedef __attribute__((address_space(3))) const sq16_t lds_sq16;

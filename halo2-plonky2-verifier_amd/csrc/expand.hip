@@ -389,7 +389,7 @@ template <int L, bool ROAM, bool COLS> __global__ __launch_bounds__(EXPAND_THREA
                 }
             }
             // flush, record-major: a group of four records is written out completely (NCH steps of 256 B per record) before the next group -
-            // a wavefront's stores must sweep memory sequentially (tools/ubench_store6.hip: revisiting a record later costs a third of the rate)
+            // a wavefront's stores must sweep memory sequentially (tools/ubench/ubench_store6.hip: revisiting a record later costs a third of the rate)
 #pragma unroll 1
             for (int g = 0; g < FAST_T / 4; g++) {
                 const uint2 br = s_vbr[wv][g * 4 + (lane >> 4)];

@@ -1,0 +1,21 @@
+#!/bin/bash
+# ONE parametrised experiment runner (the round-1/2 one-off scripts are in the git history; what each measured and where its result lives: README.md here).
+#
+#   variant.sh NAME "EXTRA_CXX_FLAGS" -- COMMAND...
+#       builds halo2-plonky2-verifier_amd/libh2w_NAME.so with the extra compiler flags (compile-time knobs of the kernels: -DH2W_FAST_T=8,
+#       -DH2W_QUAD_BLOCK=512, -DH2W_QUAD_EU=1, -DH2W_FAST_K=2 ...) and runs COMMAND with H2W_LIB pointing at it.  NAME "" = the product library.
+#   variant.sh - "" -- python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras [--chain-passes 1|2] [--streams N] [--batch B] [--no-fork] ...
+#       run-time knobs need no build: they are bench.py flags / h2w_plan_configure options.
+#   variant.sh pmc "" -- rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_WR \
+#              -d gpurun_out/pmc -o r --output-format csv -- python3 tools/launch_timing.py --batch 64 --passes 2
+#
+# Build on the CPU container (hipcc cross-compiles), run through gpurun: the built .so travels with the snapshot.  A variant library is scaffolding:
+# nothing in tests/, bench.py's defaults or __graft_entry__.py loads one, and its cells may be garbage when a flag removes work.
+set -e
+name=$1; flags=$2; shift 2; [ "$1" = "--" ] && shift
+root="$(cd "$(dirname "$0")/../.." && pwd)"
+if [ -n "$name" ] && [ "$name" != "-" ] && [ "$name" != "pmc" ]; then
+  [ -f "$root/halo2-plonky2-verifier_amd/libh2w_$name.so" ] || H2W_EXTRA="$flags" "$root/tools/build_debug_variant.sh" "$name"
+  export H2W_LIB="$root/halo2-plonky2-verifier_amd/libh2w_$name.so"
+fi
+cd "$root" && exec "$@"

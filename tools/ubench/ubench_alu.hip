@@ -1,5 +1,5 @@
 // Micro-benchmark: issue rates of the integer / fp64 ops a 254-bit Montgomery product can be built from (gfx950).
-// hipcc -O3 --offload-arch=gfx950 tools/ubench_alu.hip -o /tmp/ubench_alu && /tmp/ubench_alu
+// hipcc -O3 --offload-arch=gfx950 tools/ubench/ubench_alu.hip -o /tmp/ubench_alu && /tmp/ubench_alu
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -7,7 +7,7 @@
 //   P4  lane = 16-B piece of ONE record: 1 KB contiguous per instruction (3 instructions per record, the last one partial)
 //   P5  lane = 16-B piece of TWO records: 512 B contiguous each
 //   P6  P4 with the tile's records interleaved over time like P2 (chunk-major, 1 KB chunks)
-// hipcc -O3 --offload-arch=gfx950 tools/ubench_store3.hip -o /tmp/ubench_store3 && /tmp/ubench_store3
+// hipcc -O3 --offload-arch=gfx950 tools/ubench/ubench_store3.hip -o /tmp/ubench_store3 && /tmp/ubench_store3
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
