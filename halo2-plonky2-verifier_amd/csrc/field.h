@@ -13,16 +13,20 @@
 // HNI: out-of-line by default (the gadget stack is instantiated over five backends; code size).  A translation unit that
 // defines H2W_FLATTEN_CHIPS gets them inlinable: its kernel is then flattened so that the sink state lives in registers - every
 // AMDGPU function call starts with s_waitcnt vmcnt(0) and reaches its object through flat loads (see glue.hip).
+// HNI is for members of templates over a BACKEND only: the flattened unit instantiates backends no other unit does (glue.hip), so no inline
+// function exists with two different definitions.  A non-template function that must stay out of line uses HOL, the same in every unit.
 #if defined(H2W_FLATTEN_CHIPS)
 #define HNI __host__ __device__ inline
 #else
 #define HNI __host__ __device__ __attribute__((noinline))
 #endif
+#define HOL __host__ __device__ __attribute__((noinline))
 #else
 #define HD inline
 #define HDN
 #define HF inline
 #define HNI __attribute__((noinline))
+#define HOL __attribute__((noinline))
 #endif
 
 namespace h2w {

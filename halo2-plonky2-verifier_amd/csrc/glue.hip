@@ -16,6 +16,7 @@
 
 namespace h2w {
 
+// (the backends of this unit - DevSinkT<COLS, true> and CoopSinkT<COLS, true, -1> - are instantiated nowhere else: field.h, HNI)
 template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_strands(BatchArgs A) {
     typedef DevSinkT<COLS, true> GlueSink; typedef ValBackend<GlueSink> GlueB;
     int p, q;

@@ -30,7 +30,7 @@ struct ColMap { const uint64_t *starts; uint32_t ncols, k; };
 struct ColCursor {
     ColMap m; uint64_t lo, hi; uint64_t delta;      // cells in [lo, hi) map to cell + delta (mod 2^64)
     HD void init(const ColMap &cm) { m = cm; lo = 0; hi = cm.starts ? 0 : ~0ull; delta = 0; }
-    HNI void locate(uint64_t cell) {      // rare (once per column a strand enters): kept out of line
+    HOL void locate(uint64_t cell) {      // rare (once per column a strand enters): kept out of line
         uint32_t a = 0, b = m.ncols;                   // largest c with starts[c] <= cell
         while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (g_load_u64(m.starts + mid) <= cell) a = mid; else b = mid; }
         lo = g_load_u64(m.starts + a); hi = a + 1 < m.ncols ? g_load_u64(m.starts + a + 1) : ~0ull;

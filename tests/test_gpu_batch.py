@@ -503,3 +503,44 @@ def test_comm_world_of_one(h2w, h2w_api):
     with pytest.raises(RuntimeError):
         comm.broadcast_proofs(proofs, root=1)
     comm.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_two_ranks_over_rccl(h2w, h2w_api, oracle, consts, mode, tmp_path):
+    """The multi-rank path on real hardware (needs two GPUs: skipped on the one-GPU test box, where RCCL refuses two ranks on one device): two fresh
+    processes, one per GPU - h2w_comm_init over RCCL, ONE broadcast of the proof block from rank 0, h2w_fri_witness_batch_shard_compact on each
+    rank, all-gather of the digests of the ranks' packed buffers - every rank ends with both digests, and each equals the checksum of that rank's
+    blocks of the oracle's streams."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ko, kh = consts
+    n, world = 3, 2
+    here = os.path.dirname(os.path.abspath(__file__))
+    idf = str(tmp_path / "comm.id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_comm_rank.py"), str(r), str(world), idf, str(mode), str(n)], stdout=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [json.loads(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert outs[0]["digests"] == outs[1]["digests"] and outs[0]["proof_checksum"] == outs[1]["proof_checksum"]
+    assert all(o["status"] == [0] * n for o in outs)
+    sh = h2w.fibonacci_shape(7, 5, rate_bits=2, hash_mode=mode); osh = oracle.fibonacci_shape(7, 5, rate_bits=2, hash_mode=mode)
+    plan = h2w_api.Plan(sh, kh)
+    streams = []
+    for i in range(n):
+        ctx = oracle.Ctx(21, track_scopes=False)
+        assert oracle.verify_stark(ctx, osh, ko, oracle.synth_proof(osh, 900 + i)) == 0
+        streams.append(np.frombuffer(ctx.advice_bytes(), dtype=np.uint64).reshape(-1, 4).copy()); ctx.close()
+    for rank in range(world):
+        packed = np.zeros((plan.shard_cells(n, rank, world), 4), dtype=np.uint64)
+        for p_ in range(n):
+            for q in range(-1, sh.num_queries):
+                blk = plan.shard_block(rank, world, p_, q)
+                if blk is not None:
+                    packed[blk[0]:blk[0] + blk[1]] = streams[p_][blk[2]:blk[2] + blk[1]]
+        assert outs[0]["digests"][4 * rank:4 * rank + 4] == h2w_api.advice_digest_reference(packed), rank
+    plan.close()

@@ -75,6 +75,40 @@ def test_query_unit_partition_is_exact():
         assert max(map(len, shares)) - min(map(len, shares)) <= 1
 
 
+def test_packed_shard_layout_arithmetic():
+    """h2w_plan_shard_cells / h2w_plan_shard_block (host arithmetic, no device): a rank's packed buffer holds exactly the blocks the round-robin deal
+    gives it (distributed.shard_ranges), back to back without overlap; over the ranks every cell of every proof has one owner.  The device side of
+    the same arithmetic (batchargs.h block_out, expand.hip fast_tile_range) is compared with the oracle in tests/test_gpu_batch.py::test_packed_shard_layout."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    h2w = importlib.import_module("halo2-plonky2-verifier_amd"); api = importlib.import_module("halo2-plonky2-verifier_amd.api")
+    D = importlib.import_module("halo2-plonky2-verifier_amd.distributed")
+    for mode in (1, 0):
+        sh = h2w.fibonacci_shape(6, 5, hash_mode=mode)
+        plan = api.Plan(sh, h2w.published_consts())
+        layout = plan.strand_layout()
+        for n, world in [(3, 2), (5, 3), (2, 8), (7, 1), (9, 4)]:
+            seen = {}
+            for rank in range(world):
+                cells = plan.shard_cells(n, rank, world)
+                blocks = []
+                for p in range(n):
+                    for q in range(-1, sh.num_queries):
+                        b = plan.shard_block(rank, world, p, q)
+                        if b is not None:
+                            blocks.append((b[0], b[1], p, b[2]))
+                blocks.sort()
+                assert all(blocks[i][0] + blocks[i][1] <= blocks[i + 1][0] for i in range(len(blocks) - 1))      # no overlap, in (proof, block) order
+                assert blocks[-1][0] + blocks[-1][1] <= cells and blocks[0][0] == 0
+                assert cells - sum(b[1] for b in blocks) <= n * sh.num_queries                                    # slack: at most one cell per query slot
+                assert sorted((p, g, c) for _, c, p, g in blocks) == sorted(D.shard_ranges(n, sh.num_queries, rank, world, layout))
+                for _, c, p, g in blocks:
+                    for key in ((p, g), (p, g + c - 1)):
+                        assert key not in seen; seen[key] = rank
+            assert sum(plan.shard_cells(n, r, world) for r in range(world)) >= n * plan.num_cells
+        plan.close()
+
+
 def _shard_worker(rank, world, port, n, out):
     """One rank of a query-sharded run, on the CPU: the broadcast, the host-side partition (Plan.strand_layout + shard_ranges:
     what h2w_fri_witness_batch_shard's kernels follow on the device) and this rank's cells - cut out of the oracle's stream, which
