@@ -72,12 +72,6 @@ struct PlanSink {
     void query_end(int q, uint64_t) { if (q <= 1) { st->q_nrec[q] = nrec - cur_q_rec; st->q_ncell[q] = cell_off - cur_q_cell; st->q_nunit[q] = nunit - cur_q_unit; st->q_nglp = (uint32_t)(nglp - cur_q_glp); } }
 };
 
-// The PoseidonBN254 emission kernel: two blocks of QUAD_BLOCK threads per CU by LDS (32.9 KB of tables + 10 KB of value slots per wavefront)
-#ifndef H2W_QUAD_EU
-#define H2W_QUAD_EU 2
-#endif
-#define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(H2W_QUAD_EU, H2W_QUAD_EU)))
-
 // WitnessChip::load_proof_with_pis (witness/mod.rs:267-294) and the limb decompositions of the caps' BN254 hashes (challenger/mod.rs:65-74,
 // hash/poseidon_bn254/hash.rs:31-43): every item is a function of a few proof words - one lane per (proof, item).  Every rank checks every
 // proof's words (status 4); the proof's owner writes the records and cells.
@@ -114,15 +108,15 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_glp_emit(BatchArgs 
     typedef CoopSinkT<COLS, false> Sink;
     stage_glp_consts(A.consts, threadIdx.x, 64);
     unsigned b = blockIdx.x; int p, slot;
-    const unsigned n_pro = A.sh.n_own_proofs * A.st.pro_nglp;
-    if (b < n_pro) { p = (int)(b / A.st.pro_nglp) * A.sh.world + A.sh.rank; slot = (int)(b % A.st.pro_nglp); }
+    const unsigned n_pro = A.sh.n_own_proofs * A.st->pro_nglp;
+    if (b < n_pro) { p = (int)(b / A.st->pro_nglp) * A.sh.world + A.sh.rank; slot = (int)(b % A.st->pro_nglp); }
     else {
         b -= n_pro; int q;
-        if (A.st.q_nglp == 0 || !own_unit_at(A, b / A.st.q_nglp, p, q)) return;
-        slot = (int)(A.st.pro_nglp + (unsigned)q * A.st.q_nglp + b % A.st.q_nglp);
+        if (A.st->q_nglp == 0 || !own_unit_at(A, b / A.st->q_nglp, p, q)) return;
+        slot = (int)(A.st->pro_nglp + (unsigned)q * A.st->q_nglp + b % A.st->q_nglp);
     }
     Sink sink; coop_sink_init(sink, A, p, -1); sink.cell_off = 0; sink.emit = true;
-    const uint64_t *e = A.glp_list + ((uint64_t)p * A.st.total_glp + (uint64_t)slot) * GLP_LIST_WORDS;
+    const uint64_t *e = A.glp_list + ((uint64_t)p * A.st->total_glp + (uint64_t)slot) * GLP_LIST_WORDS;
     const uint64_t w = threadIdx.x < GLP_LIST_WORDS ? g_load_u64(e + threadIdx.x) : 0;
     uint64_t st[SPONGE_WIDTH];
 #pragma unroll
@@ -142,10 +136,11 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(Ba
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     Sink sink; coop_sink_init(sink, A, p, q); sink.emit = true;
-    sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
-    sink.glp_slot = A.st.pro_nglp + (uint32_t)q * A.st.q_nglp + A.st.mk_glp_rel[kind];
+    sink.nrec = strand_q_rec(*A.st, q) + A.st->mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(*A.st, q) + A.st->mk_cell_rel[sq][kind];
+    sink.glp_slot = A.st->pro_nglp + (uint32_t)q * A.st->q_nglp + A.st->mk_glp_rel[kind];
     CoopB be(sink, make_cfg(A, p), true);
-    Verifier<CoopB> V(be, A.shape, A.consts);
+    const h2w_shape_t shp = A.shape;      // (a reference into the kernel arguments would put all of them on every lane's stack)
+    Verifier<CoopB> V(be, shp, A.consts);
     const uint64_t x = A.cbs[p].fri_query_indices[q];
     const int lde = V.d.lde_bits; int lo = 0;
     if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
@@ -154,23 +149,6 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(Ba
     if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
-// PoseidonBN254 Merkle chains (hash_mode 1).  A quad's strand: (owned unit, kind); its cursor, index bits and unit buffer.
-template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(const BatchArgs &A, Sink &sink, int p, int q, int kind) {
-    const int sq = q == 0 ? 0 : 1;
-    sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
-    sink.nrec = strand_q_rec(A.st, q) + A.st.mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(A.st, q) + A.st.mk_cell_rel[sq][kind];
-    const uint64_t unit0 = (uint64_t)p * A.st.total_unit + strand_q_unit(A.st, q) + A.st.mk_unit_rel[sq][kind];
-    sink.ustate = A.unit_state + unit0 * 4; sink.sbx = A.unit_sbox + unit0 * (BN_PARTIAL_ROUNDS * 3);
-    ValCfg mc = make_cfg(A, p); mc.split_bn = true;
-    QuadB be(sink, mc, !(q == 0 && kind == A.st.first_zero_kind));
-    Verifier<QuadB> V(be, A.shape, A.consts);
-    const uint64_t x = A.cbs[p].fri_query_indices[q];
-    const int lde = V.d.lde_bits; int lo = 0;
-    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
-    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
-    V.merkle_strand(q, kind, PackedBits{x, lo}, lde - lo, cap_index);
-    if ((threadIdx.x & 3) == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
-}
 // values phase: four lanes per (owned unit, kind); blockIdx.y = kind slot
 __global__ __launch_bounds__(QUAD_BLOCK) void k_merkle_bn_values(BatchArgs A) {
     typedef QuadSinkT<false, QUAD_VALUES> Sink; typedef ValBackend<Sink> QuadB;
@@ -200,28 +178,6 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void
     Sink sink;
     quad_strand<QuadB>(A, sink, p, q, kind);
 }
-// emission: four lanes per work item = (strand kind, permutation unit of that strand; owned unit).  The quads of a wavefront share
-// the (kind, unit) and differ in the (proof, query): they reach their unit's permutation together (a wavefront whose quads emitted
-// at different levels would run every one of those emissions with four lanes active).
-template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void k_merkle_bn_emit(BatchArgs A) {
-    typedef QuadSinkT<COLS, QUAD_EMIT> Sink; typedef ValBackend<Sink> QuadB;
-    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);
-    const unsigned per_q = A.st.mk_item0[MK_KINDS], upad = (A.sh.n_own_units + 15u) & ~15u;      // 16 quads = one wavefront per 16 units of an item
-    const unsigned long long total = (unsigned long long)per_q * upad;
-    const unsigned long long g = ((unsigned long long)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
-    if (g >= total) return;                                       // (whole wavefronts: total is a multiple of 16)
-    // items outermost: the wavefronts in flight at one time work on the same few levels of every path of the launch (grouping all levels of a
-    // few hundred units instead - a compact part of the advice - was slower: 6.65 against 5.74 ms, profiles/r03_emit_store_bound.txt)
-    const unsigned item = (unsigned)(g / upad); unsigned ui = (unsigned)(g % upad);
-    if (ui >= A.sh.n_own_units) ui = A.sh.n_own_units - 1;      // tail quads of an item redo its last unit (identical bytes)
-    int p, q; own_unit_at(A, ui, p, q);
-    int kind = 0;
-#pragma unroll 1
-    for (int k = 1; k < MK_KINDS; k++) if (item >= A.st.mk_item0[k]) kind = k;      // (kinds a shape does not have own no items)
-    Sink sink; sink.set_window((int)(item - A.st.mk_item0[kind]), (int)A.st.mk_nunit[kind]);
-    quad_strand<QuadB>(A, sink, p, q, kind);
-}
-
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -251,6 +207,7 @@ struct h2w_plan {
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
     PlanEqualities eqs;
     fr_t *d_bn_tab = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
+    StrandTable *d_st = nullptr;                      // device copy of st
     bool small_mds = false;                           // Goldilocks-Poseidon MDS entries are tiny (coop.h glp_small_mds)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
     static constexpr int EV_RING = 64, N_EV = 13, N_SIDE = 16;
@@ -349,6 +306,8 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             H2W_HIP(hipMalloc((void **)&pl->d_bn_tab, tab.size() * sizeof(fr_t)));
             H2W_HIP(hipMemcpy(pl->d_bn_tab, tab.data(), tab.size() * sizeof(fr_t), hipMemcpyHostToDevice));
         }
+        H2W_HIP(hipMalloc((void **)&pl->d_st, sizeof(StrandTable)));
+        H2W_HIP(hipMemcpy(pl->d_st, &pl->st, sizeof(StrandTable), hipMemcpyHostToDevice));
         H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t)));
         H2W_HIP(hipMemcpy(pl->d_consts, consts, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
         std::vector<uint16_t> nc(T_MAX, 0); for (size_t i = 0; i < pl->tt.info.size(); i++) nc[i] = pl->tt.info[i].ncells;
@@ -370,6 +329,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
     if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->d_st) (void)hipFree(p->d_st);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->d_lookup_cells) (void)hipFree(p->d_lookup_cells);
@@ -517,7 +477,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
     A.bn_tab = p->d_bn_tab;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.n_cap_items = p->n_cap_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell; A.load_flag = (uint32_t *)(ws + wl.lflag);
-    A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->st; A.P = p->P; A.nproofs = (int)n_proofs;
+    A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->d_st; A.P = p->P; A.nproofs = (int)n_proofs;
     A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p);
     A.sh.n_own_units = (uint32_t)own_count(n_proofs * (uint64_t)p->shape.num_queries, sh.rank, sh.world);
     A.sh.n_own_proofs = (uint32_t)own_count(n_proofs, sh.rank, sh.world);
@@ -573,7 +533,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             const unsigned long long items = passes == 1 ? 0ull : (unsigned long long)((nunits + 15u) & ~15u) * p->st.mk_item0[MK_KINDS];
             if (items) {
                 const dim3 egrid((unsigned)((items * 4 + QUAD_BLOCK - 1) / QUAD_BLOCK));
-                if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_emit<true>, egrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_emit<false>, egrid, dim3(QUAD_BLOCK), 0, cstream, A);
+                launch_merkle_bn_emit(A, egrid, cstream);
             }
             H2W_HIP(hipEventRecord(ev[5], cstream));
         }

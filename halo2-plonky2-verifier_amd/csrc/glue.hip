@@ -2,6 +2,8 @@
 //   k_strands          the query glue: FriChip::verify_query_round minus its Merkle proofs (fri/mod.rs:338-444: index bits, subgroup_x,
 //                      combine_initial, per fold step the consistency select, compute_evaluation / interpolate_coset and x^arity,
 //                      final-polynomial evaluation), one lane per (proof, query);
+//   k_merkle_bn_emit   the level-parallel PoseidonBN254 emission: a quad steps over its strand to its own unit (merkle/mod.rs:57-78) - out of line that walk
+//                      kept a 3 KB stack per lane, and 10752 wavefronts x 198 KB of it was 3 GB of scratch traffic per launch beside 22 GB of cells;
 //   k_prologue_values  the prologue on values (stark/mod.rs:497-508, challenger/mod.rs:168-222, fri/mod.rs:45-62,130-145), one wavefront per proof.
 //
 // Their own translation unit because the gadget stack is compiled FLATTENED here (H2W_FLATTEN_CHIPS): a strand is a serial program of
@@ -22,10 +24,11 @@ template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) v
     int p, q;
     if (!own_unit_at(A, blockIdx.x * blockDim.x + threadIdx.x, p, q)) return;      // lane i of the launch = this rank's i-th (proof, query) unit
     GlueSink sink; sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.cc.init(A.cm);
-    sink.nrec = strand_q_rec(A.st, q); sink.cell_off = strand_q_cell(A.st, q);
+    sink.nrec = strand_q_rec(*A.st, q); sink.cell_off = strand_q_cell(*A.st, q);
     const ChallengeBlock<GlueB> &cb = *reinterpret_cast<const ChallengeBlock<GlueB> *>(&A.cbs[p]);
     GlueB be(sink, make_cfg(A, p), true);
-    Verifier<GlueB> V(be, A.shape, A.consts);
+    const h2w_shape_t shp = A.shape;      // (a reference into the kernel arguments would put all of them on every lane's stack)
+    Verifier<GlueB> V(be, shp, A.consts);
     V.query_round(q, cb);
     if (be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
@@ -40,9 +43,37 @@ template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) v
     Sink sink; coop_sink_init(sink, A, p, -1); sink.nrec = 0; sink.cell_off = 0; sink.glp_slot = 0;
     sink.emit = own_prologue(A, p);
     CoopB be(sink, make_cfg(A, p), true);
-    Verifier<CoopB> V(be, A.shape, A.consts);
+    const h2w_shape_t shp = A.shape;      // (a reference into the kernel arguments would put all of them on every lane's stack)
+    Verifier<CoopB> V(be, shp, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
     if (threadIdx.x == 0) A.status[p] = be.status;
+}
+
+// emission: four lanes per work item = (strand kind, permutation unit of that strand; owned unit).  The quads of a wavefront share
+// the (kind, unit) and differ in the (proof, query): they reach their unit's permutation together (a wavefront whose quads emitted
+// at different levels would run every one of those emissions with four lanes active).
+template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR __attribute__((flatten)) void k_merkle_bn_emit(BatchArgs A) {
+    typedef QuadSinkT<COLS, QUAD_EMIT> Sink; typedef ValBackend<Sink> QuadB;
+    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);
+    const unsigned per_q = A.st->mk_item0[MK_KINDS], upad = (A.sh.n_own_units + 15u) & ~15u;      // 16 quads = one wavefront per 16 units of an item
+    const unsigned long long total = (unsigned long long)per_q * upad;
+    const unsigned long long g = ((unsigned long long)blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
+    if (g >= total) return;                                       // (whole wavefronts: total is a multiple of 16)
+    // items outermost: the wavefronts in flight at one time work on the same few levels of every path of the launch (grouping all levels of a
+    // few hundred units instead - a compact part of the advice - was slower: 6.65 against 5.74 ms, profiles/r03_emit_store_bound.txt)
+    const unsigned item = (unsigned)(g / upad); unsigned ui = (unsigned)(g % upad);
+    if (ui >= A.sh.n_own_units) ui = A.sh.n_own_units - 1;      // tail quads of an item redo its last unit (identical bytes)
+    int p, q; own_unit_at(A, ui, p, q);
+    int kind = 0;
+#pragma unroll 1
+    for (int k = 1; k < MK_KINDS; k++) if (item >= A.st->mk_item0[k]) kind = k;      // (kinds a shape does not have own no items)
+    Sink sink; sink.set_window((int)(item - A.st->mk_item0[kind]), (int)A.st->mk_nunit[kind]);
+    quad_strand<QuadB>(A, sink, p, q, kind);
+}
+
+void launch_merkle_bn_emit(const BatchArgs &A, dim3 grid, hipStream_t stream) {
+    if (A.cm.starts) hipLaunchKernelGGL(k_merkle_bn_emit<true>, grid, dim3(QUAD_BLOCK), 0, stream, A);
+    else hipLaunchKernelGGL(k_merkle_bn_emit<false>, grid, dim3(QUAD_BLOCK), 0, stream, A);
 }
 
 void launch_prologue_values(const BatchArgs &A, hipStream_t stream) {
