@@ -64,14 +64,15 @@ def test_chain_round_loops_have_no_scratch_or_flat_accesses(tmp_path):
     for c, d in full:
         _clean(lines, c, d, "one-pass full-round loop")
     # emission kernel of the two-pass paths (k_merkle_bn_emit): two products per partial round, rounds in pairs (644 multiply-adds per trip),
-    # the S-box values requested a pair ahead: no vector-memory wait but the two that admit the next pair's loads
-    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi2EE13bn_emit_cellsILb1EE")
-    loops = list(_loops(lines, lo, hi))
-    pair = [(a, b) for a, b in loops if 630 <= _count(lines, a, b, "v_mad_u64_u32") <= 660]
+    # the S-box values requested a pair ahead: no vector-memory wait but the two that admit the next pair's loads.  (The kernel lives in glue.hip.)
+    glue = _asm("glue.hip", tmp_path)
+    lo, hi = _function(glue, "_ZN3h2w9QuadSinkTILb0ELi2EE13bn_emit_cellsILb1EE")
+    loops = list(_loops(glue, lo, hi))
+    pair = [(a, b) for a, b in loops if 630 <= _count(glue, a, b, "v_mad_u64_u32") <= 660]
     assert pair, "two-round loop (four products) not found"
     a, b = min(pair, key=lambda ab: ab[1] - ab[0])
-    _clean(lines, a, b, "emission partial-round loop")
-    waits = [int(m.group(1)) for l in lines[a:b + 1] for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)] if m]
+    _clean(glue, a, b, "emission partial-round loop")
+    waits = [int(m.group(1)) for l in glue[a:b + 1] for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)] if m]
     assert waits and min(waits) >= 30, f"a vector-memory wait in the emission loop drains the store queue: vmcnt {waits}"
     # values kernel (k_merkle_bn_values): no scratch in its round loops either
     lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi1EE9bn_values")
