@@ -152,7 +152,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(Ba
 // values phase: four lanes per (owned unit, kind); blockIdx.y = kind slot
 __global__ __launch_bounds__(QUAD_BLOCK) void k_merkle_bn_values(BatchArgs A) {
     typedef QuadSinkT<false, QUAD_VALUES> Sink; typedef ValBackend<Sink> QuadB;
-    stage_bn_consts(A.bn_tab, threadIdx.x, QUAD_BLOCK);      // (block-wide barrier inside: before any wavefront leaves)
+    stage_bn_consts9(A.bn_tab9, threadIdx.x, QUAD_BLOCK);    // (block-wide barrier inside: before any wavefront leaves)
     const unsigned total = A.sh.n_own_units;
     if (((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;      // a wavefront past the last strand
     unsigned idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
@@ -162,6 +162,17 @@ __global__ __launch_bounds__(QUAD_BLOCK) void k_merkle_bn_values(BatchArgs A) {
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     Sink sink;
     quad_strand<QuadB>(A, sink, p, q, kind);
+}
+// between the two passes: the S-box values of the owned units' partial rounds, as the values pass left them (times R), to the canonical
+// values the emission shows - one lane per value, 168 per permutation unit
+__global__ __launch_bounds__(256) void k_sbox_canon(BatchArgs A, uint32_t units_per_query) {
+    const uint64_t per_q = (uint64_t)units_per_query * (BN_PARTIAL_ROUNDS * 3);
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned i = (unsigned)(idx / per_q); const uint64_t v = idx % per_q;
+    int p, q; if (!own_unit_at(A, i, p, q)) return;
+    if (v >= A.st->q_nunit[q == 0 ? 0 : 1] * (uint64_t)(BN_PARTIAL_ROUNDS * 3)) return;
+    fr_t *const x = A.unit_sbox + ((uint64_t)p * A.st->total_unit + strand_q_unit(*A.st, q)) * (BN_PARTIAL_ROUNDS * 3) + v;
+    g_store_fr(x, fr_mont_mul(g_load_fr(x), fr_from_u64(1), A.P.ninv));
 }
 // one pass (H2W_OPT_CHAIN_PASSES 1): four lanes per (owned unit, kind) walk the path and emit every unit of it - the least arithmetic per
 // cell (352 wavefront-level products per permutation, none twice), serial in the path's depth; blockIdx.y = kind slot
@@ -206,7 +217,7 @@ struct h2w_plan {
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
     PlanEqualities eqs;
-    fr_t *d_bn_tab = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
+    fr_t *d_bn_tab = nullptr; uint32_t *d_bn_tab9 = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
     StrandTable *d_st = nullptr;                      // device copy of st
     bool small_mds = false;                           // Goldilocks-Poseidon MDS entries are tiny (coop.h glp_small_mds)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
@@ -302,9 +313,12 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             H2W_HIP(hipMemcpy(pl->d_items, items.data(), items.size() * sizeof(LoadItem), hipMemcpyHostToDevice));
         }
         {   // PoseidonBN254 tables: canonical and R-premultiplied, per plan (two plans with different tables never share state)
-            std::vector<fr_t> tab(2 * BK_T); bn_table_build(*consts, pl->P, tab.data());
+            std::vector<fr_t> tab(BK_ALL); bn_table_build(*consts, pl->P, tab.data());
             H2W_HIP(hipMalloc((void **)&pl->d_bn_tab, tab.size() * sizeof(fr_t)));
             H2W_HIP(hipMemcpy(pl->d_bn_tab, tab.data(), tab.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+            std::vector<uint32_t> tab9((size_t)BK9_N * BK9_W); bn_table9_build(tab.data(), tab9.data());      // the values pass' limb-form copy
+            H2W_HIP(hipMalloc((void **)&pl->d_bn_tab9, tab9.size() * sizeof(uint32_t)));
+            H2W_HIP(hipMemcpy(pl->d_bn_tab9, tab9.data(), tab9.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
         H2W_HIP(hipMalloc((void **)&pl->d_st, sizeof(StrandTable)));
         H2W_HIP(hipMemcpy(pl->d_st, &pl->st, sizeof(StrandTable), hipMemcpyHostToDevice));
@@ -328,6 +342,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_meta) (void)hipFree(p->d_meta);
     if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
+    if (p->d_bn_tab9) (void)hipFree(p->d_bn_tab9);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_st) (void)hipFree(p->d_st);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
@@ -475,7 +490,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.recs = (rec_t *)(ws + wl.recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
     A.cbs = (DevCB *)(ws + wl.cbs); A.status = (uint32_t *)(ws + wl.status);
     A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
-    A.bn_tab = p->d_bn_tab;
+    A.bn_tab = p->d_bn_tab; A.bn_tab9 = p->d_bn_tab9;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.n_cap_items = p->n_cap_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell; A.load_flag = (uint32_t *)(ws + wl.lflag);
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->d_st; A.P = p->P; A.nproofs = (int)n_proofs;
     A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p);
@@ -528,7 +543,12 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             const int passes = p->chain_passes ? p->chain_passes : (nunits <= 512 ? 2 : 1);
             p->passes_of[p->n_batches % h2w_plan::EV_RING] = passes;
             if (nunits && passes == 1) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_fused<true>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_fused<false>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
-            if (nunits && passes != 1) hipLaunchKernelGGL(k_merkle_bn_values, sgrid, dim3(QUAD_BLOCK), 0, cstream, A);
+            if (nunits && passes != 1) {
+                hipLaunchKernelGGL(k_merkle_bn_values, sgrid, dim3(QUAD_BLOCK), 0, cstream, A);
+                const uint32_t upq = (uint32_t)(p->st.q_nunit[0] > p->st.q_nunit[1] ? p->st.q_nunit[0] : p->st.q_nunit[1]);
+                const uint64_t nval = (uint64_t)nunits * upq * (BN_PARTIAL_ROUNDS * 3);
+                if (nval) hipLaunchKernelGGL(k_sbox_canon, dim3((unsigned)((nval + 255) / 256)), dim3(256), 0, cstream, A, upq);
+            }
             H2W_HIP(hipEventRecord(ev[10], cstream));
             const unsigned long long items = passes == 1 ? 0ull : (unsigned long long)((nunits + 15u) & ~15u) * p->st.mk_item0[MK_KINDS];
             if (items) {

@@ -28,6 +28,7 @@ struct BatchArgs {
     const StrandTable *st; FrParams P;      // the shape's strand table, in device memory (a by-value copy in the kernel arguments is copied to every lane's stack as soon as it is indexed)
     int nproofs;
     const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
+    const uint32_t *bn_tab9;        // the times-R entries and the BK_X block in limb form (coop.h bn_table9_build): the values pass
     fr_t *unit_state;               // [nproofs][st.total_unit][4]: output state of every PoseidonBN254 permutation unit (values phase -> emission)
     fr_t *unit_sbox;                // [nproofs][st.total_unit][56][3]: canonical x^2, x^4, x^5 of its partial rounds' S-boxes
     uint64_t *glp_list;             // [nproofs][st.total_glp][GLP_LIST_WORDS]: the listed Goldilocks-Poseidon permutations (values phase -> record emission)

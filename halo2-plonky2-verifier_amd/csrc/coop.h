@@ -388,15 +388,19 @@ enum { BK_C = 0, BK_S = 88, BK_M = 88 + 392, BK_P = 88 + 392 + 16, BK_N = 88 + 3
 constexpr int BN_PERM_CELLS = 4032;                         // cells of one permutation (20 + 1,100 + 2,912), without the Context's one cached load_zero cell
 constexpr int BN_NSLOT = 20;                                 // value slots per quad (the widest layer, a full-round mix, stages 4 inputs + 16 partial sums)
 constexpr int BN_SLOT_SQ = 16 * 2;                           // 16-byte units per slot row: 16 quads x 32 B
-__shared__ sq16_t s_bn_tab[2 * BK_T * 2];                    // [form][entry][half]: 32.9 KB
+constexpr int BK_X = 2 * BK_T;                                // behind the two forms: S_0 c of every partial round, times R (the values pass, bn_values)
+constexpr int BK_ALL = BK_X + 56;
+__shared__ sq16_t s_bn_tab[2 * BK_T * 2];                    // [form][entry][half]: 32.9 KB (the BK_X block is only read in limb form: s_bn_tab9)
 __shared__ sq16_t s_bn_val[QUAD_WAVES * BN_NSLOT * BN_SLOT_SQ];   // [wavefront][slot][quad][half]: 10 KB per wavefront
 // host: the table a plan uploads (BatchArgs::bn_tab): canonical entries, then the same entries times R, each followed by 0 and 1
-inline void bn_table_build(const h2w_poseidon_consts_t &k, const FrParams &P, fr_t *tab /*[2 * BK_T]*/) {
+inline void bn_table_build(const h2w_poseidon_consts_t &k, const FrParams &P, fr_t *tab /*[BK_ALL]*/) {
     for (int i = 0; i < 88; i++) tab[BK_C + i] = k.bn_c[i];
     for (int i = 0; i < 392; i++) tab[BK_S + i] = k.bn_s[i];
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { tab[BK_M + 4 * i + j] = k.bn_m[i][j]; tab[BK_P + 4 * i + j] = k.bn_p[i][j]; }
     tab[BK_ZERO] = fr_zero(); tab[BK_ONE] = fr_from_u64(1);
     for (int i = 0; i < BK_T; i++) tab[BK_T + i] = fr_mont_mul(tab[i], P.r2, P.ninv);
+    // S_0 c of partial round r (first entry of its sparse row times its round constant), times R
+    for (int r = 0; r < 56; r++) tab[BK_X + r] = fr_mont_mul(tab[BK_T + BK_S + 7 * r], tab[BK_T + BK_C + 20 + r], P.ninv);
 }
 __device__ __forceinline__ void stage_bn_consts(const fr_t *tab, int tid, int nthreads) {
     const sq16_t *src = reinterpret_cast<const sq16_t *>(tab);
@@ -406,6 +410,26 @@ __device__ __forceinline__ void stage_bn_consts(const fr_t *tab, int tid, int nt
 __device__ __forceinline__ fr_t bnk(int which, int idx) {
     const sq16_t a = s_bn_tab[(which * BK_T + idx) * 2], b = s_bn_tab[(which * BK_T + idx) * 2 + 1];
     fr_t r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = b.x; r.l[3] = b.y; return r;
+}
+// The values pass (bn_values) works on nine-limb lazy values (field.h fr9_t): its own table, the times-R entries and the BK_X block in limb
+// form, 12 dwords per entry (9 used): 27 KB of LDS instead of s_bn_tab.
+constexpr int BK9_N = BK_T + 56, BK9_X = BK_T, BK9_W = 12;
+__shared__ uint32_t s_bn_tab9[BK9_N * BK9_W];
+inline void bn_table9_build(const fr_t *tab /*[BK_ALL]: bn_table_build*/, uint32_t *tab9 /*[BK9_N * BK9_W]*/) {
+    for (int i = 0; i < BK9_N; i++) {
+        const fr9_t v = fr9_from(tab[i < BK_T ? BK_T + i : BK_X + (i - BK_T)]);
+        for (int j = 0; j < BK9_W; j++) tab9[i * BK9_W + j] = j < 9 ? v.t[j] : 0u;
+    }
+}
+__device__ __forceinline__ void stage_bn_consts9(const uint32_t *tab9, int tid, int nthreads) {
+    const sq16_t *src = reinterpret_cast<const sq16_t *>(tab9); sq16_t *dst = reinterpret_cast<sq16_t *>(s_bn_tab9);
+    for (int i = tid; i < BK9_N * BK9_W / 4; i += nthreads) { sq16_t v; v.x = H2W_GLOAD64(&src[i].x); v.y = H2W_GLOAD64(&src[i].y); dst[i] = v; }
+    __syncthreads();
+}
+__device__ __forceinline__ fr9_t bnk9(int idx) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(s_bn_tab9 + idx * BK9_W), b = *reinterpret_cast<const uint4 *>(s_bn_tab9 + idx * BK9_W + 4);
+    fr9_t v; v.t[0] = a.x; v.t[1] = a.y; v.t[2] = a.z; v.t[3] = a.w; v.t[4] = b.x; v.t[5] = b.y; v.t[6] = b.z; v.t[7] = b.w; v.t[8] = s_bn_tab9[idx * BK9_W + 8];
+    return v;
 }
 // quad-local exchanges as DPP moves (quad_perm control: two bits per destination lane)
 template <int CTRL> __device__ __forceinline__ fr_t quad_dpp(const fr_t &v) {
@@ -423,6 +447,25 @@ template <int J> __device__ __forceinline__ fr_t quad_bcast(const fr_t &v) { ret
 __device__ __forceinline__ fr_t quad_up1(const fr_t &v) { return quad_dpp<0x90>(v); }                            // lane i <- lane i - 1 (lane 0 keeps its own)
 __device__ __forceinline__ fr_t quad_up2(const fr_t &v) { return quad_dpp<0x44>(v); }                            // lanes 2, 3 <- lanes 0, 1
 
+template <int CTRL> __device__ __forceinline__ fr9_t quad_dpp9(const fr9_t &v) {
+    fr9_t r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.t[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.t[i], CTRL, 0xf, 0xf, false);
+    return r;
+}
+template <int J> __device__ __forceinline__ fr9_t quad_bcast9(const fr9_t &v) { return quad_dpp9<J * 0x55>(v); }
+__device__ __forceinline__ fr9_t fr9_sel(bool c, const fr9_t &a, const fr9_t &b) {
+    fr9_t r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.t[i] = c ? a.t[i] : b.t[i];
+    return r;
+}
+__device__ __forceinline__ fr9_t fr9_add_if(bool c, const fr9_t &a, const fr9_t &b) {      // a + (c ? b : 0)
+    fr9_t r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.t[i] = a.t[i] + (c ? b.t[i] : 0u);
+    return r;
+}
 // limb-wise select: `c ? a : b` on the struct itself can be lowered to a select of two stack addresses plus a scratch load, and a scratch
 // load waits (vmcnt is in order on this family) for every cell store issued before it
 __device__ __forceinline__ fr_t fr_sel(bool c, const fr_t &a, const fr_t &b) {
@@ -656,65 +699,86 @@ template <bool COLS, int MODE> struct QuadSinkT {
             return true;
         }
     }
-    // values phase: Montgomery-form state, lane l owns element l.  x^5 = three products; a partial round = four wavefront-level
-    // products (lanes 1-3 form their terms of the sparse row beside lane 0's first S-box product; the column update and S_0 s0' share
-    // the last one); a full round = 3 + 4.  The output state (canonical) goes to the strand's unit buffer, the partial rounds' S-box
-    // values to its S-box buffer.
+    // values phase: lane l owns state element l, times R, in lazy nine-limb form (field.h fr9_t: no reduction below r, no packing between
+    // products).  x^5 = three products; a full round = 3 + 4 wavefront-level products; a partial round = THREE: the row product
+    // S_0 s0' = S_0 (x^5 + c) is formed as x^4 (s0 S_0) + S_0 c - its second factor beside the chain's second squaring, S_0 c from the table
+    // (BK9_X) - so that it does not wait for x^5; the column update of round r - 1 rides in round r's first slot.
+    // Sizes, in multiples of r (R / r = 2^7.4; fr9_mont(a, b) < a b / R + r):
+    //   full rounds: mix = sum of four products with a constant < 4 (1 + 6 / 169) r, + c < 5.3 r; X2 < 5.3^2 / 169 + 1 = 1.17 r, X4, X5 smaller;
+    //   partial rounds: s0' = X5 + c < 2.1 r; U_k = s0' S'_k < 1.02 r; s_k grows by U_k per round: < 5.3 + 56 * 1.02 = 62.5 r = 2^259.6 (top limb
+    //   < 2^28); W_j = s_j S_j < (62.5 / 169 + 1) r = 1.37 r; XA = s0 S_0 < 1.04 r; T0 = X4 XA < 1.01 r; s0 = T0 + S_0 c + W_1 + W_2 + W_3 < 6.2 r,
+    //   X2 = s0 s0 < 1.23 r; after the partial rounds X2 = s_k s_k < 62.5^2 / 169 + 1 = 24.2 r, X4 < 4.5 r, X5 = X4 s_k < 2.7 r.
+    // Operands of a product are normalised, or a sum of two normalised values against a constant (field.h).
+    // The output state (canonical) goes to the strand's unit buffer; the partial rounds' S-box values x^2, x^4, x^5 to its S-box buffer AS THEY
+    // ARE (times R, below 2 r): k_sbox_canon turns them into the canonical values the emission shows, every one of them in parallel.
     __device__ __noinline__ void bn_values(fr_t *st, const ValCfg &cfg) {
-        const int l = l4, lm = l > 0 ? l - 1 : 0; const uint64_t ninv = cfg.P.ninv;
-        const fr_t one = fr_from_u64(1); fr_t X5p = fr_zero();
+        const int l = l4, lm = l > 0 ? l - 1 : 0; const uint32_t ninv = (uint32_t)cfg.P.ninv & ((1u << 29) - 1);
         fr_t *const sbu = sbx + (uint64_t)unit_local * (BN_PARTIAL_ROUNDS * 3);
-        fr_t S = fr_mont_mul(fr_sel(l < 2, fr_sel(l == 0, st[0], st[1]), fr_sel(l == 2, st[2], st[3])), cfg.P.r2, ninv);
-        auto sbox = [&]() { const fr_t X2 = fr_mont_mul(S, S, ninv), X4 = fr_mont_mul(X2, X2, ninv); S = fr_mont_mul(X4, S, ninv); };
+        fr9_t S = fr9_mont(fr9_from(fr_sel(l < 2, fr_sel(l == 0, st[0], st[1]), fr_sel(l == 2, st[2], st[3]))), fr9_from(cfg.P.r2), ninv);
+        auto sbox = [&]() { const fr9_t X2 = fr9_mont(S, S, ninv), X4 = fr9_mont(X2, X2, ninv); S = fr9_mont(X4, S, ninv); };
         auto mix = [&](int mb) {
-            const fr_t s0 = quad_bcast<0>(S), s1 = quad_bcast<1>(S), s2 = quad_bcast<2>(S), s3 = quad_bcast<3>(S);
-            fr_t acc = fr_mont_mul(s0, bnk(1, mb + l), ninv);
-            acc = fr_add(fr_mont_mul(s1, bnk(1, mb + 4 + l), ninv), acc);
-            acc = fr_add(fr_mont_mul(s2, bnk(1, mb + 8 + l), ninv), acc);
-            S = fr_add(fr_mont_mul(s3, bnk(1, mb + 12 + l), ninv), acc);
+            const fr9_t s0 = quad_bcast9<0>(S), s1 = quad_bcast9<1>(S), s2 = quad_bcast9<2>(S), s3 = quad_bcast9<3>(S);
+            fr9_t acc = fr9_mont(s0, bnk9(mb + l), ninv);
+            acc = fr9_add(fr9_mont(s1, bnk9(mb + 4 + l), ninv), acc);
+            acc = fr9_add(fr9_mont(s2, bnk9(mb + 8 + l), ninv), acc);
+            S = fr9_norm(fr9_add(fr9_mont(s3, bnk9(mb + 12 + l), ninv), acc));
         };
-        S = fr_add(S, bnk(1, BK_C + l));
+        S = fr9_norm(fr9_add(S, bnk9(BK_C + l)));
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             if (half == 1) {
+                fr9_t s0p; for (int i = 0; i < 9; i++) s0p.t[i] = 0;      // s0' = s0^5 + c of the previous round (the same on every lane); nothing is pending before round 0
+                // the round's five table entries are read a round ahead (an LDS read that is waited for where it is used costs ~130 cycles of a
+                // wavefront that has its SIMD to itself)
+                struct RoundK { fr9_t kp, k2, k1, kc, kx; };
+                auto round_k = [&](int r) {
+                    const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                    RoundK k; k.kp = bnk9(ix - (BN_WIDTH * 2 - 1) + BN_WIDTH + lm);      // (round 0: s0p = 0, the entry read is in the table)
+                    k.k2 = bnk9(ix + (l == 1 ? 0 : l)); k.k1 = bnk9(ix + 1); k.kc = bnk9(ic); k.kx = bnk9(BK9_X + r);
+                    return k;
+                };
+                RoundK kc_ = round_k(0);
 #pragma unroll 1
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-                    // Four wavefront-level products per round; the lanes that idle beside lane 0's S-box chain turn that chain's values into
-                    // the canonical x^2, x^4, x^5 the emission shows in its cells (X / R = mont(X, 1)), so that the emission does not walk the chain again:
-                    //   A: lane 0  X2 = s0 s0         | lanes j  S_j s_j
-                    //   B: lane 0  X4 = X2 X2         | lane 1   x^2 = X2 / R       | lane 2   x^5 of the previous round = X5' / R
-                    //   C: lane 0  X5 = X4 s0 ; + c   | lane 1   x^4 = X4 / R
-                    //   E: lane 0  S_0 s0'            | lanes k  S'_k s0'
-                    const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                    //   1: lane 0  X2 = s0 s0         | lanes k  S'_k s0' of round r - 1 (its column update: s_k += ...)
+                    //   2: lane 0  X4 = X2 X2         | lane 1   XA = s0 S_0             | lanes 2, 3  S_j s_j
+                    //   3: lane 0  T0 = X4 XA         | lane 1   S_1 s_1                 | lanes 2, 3  X5 = X4 s0
+                    //   new s0 = T0 + S_0 c + S_1 s_1 + S_2 s_2 + S_3 s_3;  s0' = X5 + c
+                    const RoundK kn = round_k(r + 1 < BN_PARTIAL_ROUNDS ? r + 1 : r);
                     fr_t *const sb = sbu + (uint64_t)r * 3;
-                    const fr_t ksxm = bnk(1, ix + l);
-                    const fr_t A_ = fr_mont_mul(S, fr_sel(l == 0, S, ksxm), ninv);
-                    const fr_t X2b = quad_bcast<0>(A_);
-                    const fr_t B_ = fr_mont_mul(fr_sel(l == 2, X5p, X2b), fr_sel(l == 0, X2b, one), ninv);
-                    if (l == 1) g_store_fr(sb, B_);
-                    if (l == 2 && r > 0) g_store_fr(sb - 1, B_);
-                    const fr_t X4b = quad_bcast<0>(B_);
-                    const fr_t C_ = fr_mont_mul(X4b, fr_sel(l == 0, S, one), ninv);
-                    if (l == 1) g_store_fr(sb + 1, C_);
-                    X5p = quad_bcast<0>(C_);
-                    const fr_t s0 = fr_add(X5p, bnk(1, ic));                                                    // s0' = s0^5 + c (the same on every lane)
-                    const fr_t E_ = fr_mont_mul(s0, fr_sel(l == 0, ksxm, bnk(1, ix + BN_WIDTH + lm)), ninv);
-                    fr_t incl = fr_sel(l == 0, E_, A_);
-                    { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
-                    { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
-                    S = fr_sel(l > 0, fr_add(E_, S), quad_bcast<3>(incl));
+                    const fr9_t s0b = quad_bcast9<0>(S);
+                    const fr9_t A_ = fr9_mont(fr9_sel(l == 0, S, s0p), fr9_sel(l == 0, S, kc_.kp), ninv);
+                    if (l == 0) g_store_fr(sb, fr9_pack(A_));
+                    const fr9_t X2b = quad_bcast9<0>(A_);
+                    S = fr9_add_if(l > 0, S, A_);                                       // lanes k: a sum of two until the end of the round
+                    const fr9_t B_ = fr9_mont(fr9_sel(l == 0, X2b, fr9_sel(l == 1, s0b, S)), fr9_sel(l == 0, X2b, kc_.k2), ninv);
+                    if (l == 0) g_store_fr(sb + 1, fr9_pack(B_));
+                    const fr9_t X4b = quad_bcast9<0>(B_), XAb = quad_bcast9<1>(B_);
+                    const fr9_t C_ = fr9_mont(fr9_sel(l == 1, S, X4b), fr9_sel(l == 0, XAb, fr9_sel(l == 1, kc_.k1, s0b)), ninv);
+                    if (l == 2) g_store_fr(sb + 2, fr9_pack(C_));
+                    s0p = fr9_add(quad_bcast9<2>(C_), kc_.kc);                          // a sum of two: only ever multiplied by a constant
+                    fr9_t incl = fr9_add_if(l == 0, fr9_sel(l < 2, C_, B_), kc_.kx);    // T0 + S_0 c, S_1 s_1, S_2 s_2, S_3 s_3
+                    incl = fr9_add_if(l >= 1, incl, quad_dpp9<0x90>(incl));
+                    incl = fr9_add_if(l >= 2, incl, quad_dpp9<0x44>(incl));
+                    S = fr9_norm(fr9_sel(l == 0, quad_bcast9<3>(incl), S));
+                    kc_ = kn;
                 }
-                { const fr_t x5c = fr_mont_mul(X5p, one, ninv); if (l == 2) g_store_fr(sbu + (uint64_t)(BN_PARTIAL_ROUNDS - 1) * 3 + 2, x5c); }      // the last round's x^5
+                {   // the last round's column update
+                    const fr9_t U = fr9_mont(s0p, bnk9(BK_S + (BN_WIDTH * 2 - 1) * (BN_PARTIAL_ROUNDS - 1) + BN_WIDTH + lm), ninv);
+                    S = fr9_norm(fr9_add_if(l > 0, S, U));
+                }
             }
 #pragma unroll 1
             for (int r = 0; r < BN_FULL_ROUNDS / 2; r++) {
                 const bool last = r == BN_FULL_ROUNDS / 2 - 1;
                 sbox();
-                if (!(half == 1 && last)) S = fr_add(S, bnk(1, BK_C + (half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH) + l));
+                if (!(half == 1 && last)) S = fr9_add(S, bnk9(BK_C + (half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH) + l));
                 mix(half == 0 && last ? BK_P : BK_M);
             }
         }
-        const fr_t s = fr_mont_mul(S, one, ninv);                                          // back to canonical
+        fr9_t one9; for (int i = 0; i < 9; i++) one9.t[i] = i == 0 ? 1u : 0u;
+        fr_t s = fr9_pack(fr9_mont(S, one9, ninv));                                        // back to canonical: S / R < r + 1
+        if (fr_geq_mod(s)) s = fr_sub_mod_raw(s);
         g_store_fr(ustate + (uint64_t)unit_local * 4 + l, s);
         st[0] = quad_bcast<0>(s); st[1] = quad_bcast<1>(s); st[2] = quad_bcast<2>(s); st[3] = quad_bcast<3>(s);
     }

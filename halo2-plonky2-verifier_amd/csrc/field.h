@@ -217,6 +217,96 @@ HD fr_t fr_mont_mul(const fr_t &A, const fr_t &B, uint64_t ninv) {
     if (fr_geq_mod(r)) r = fr_sub_mod_raw(r);
     return r;
 }
+// The same product on values that STAY in nine 29-bit limbs and are never reduced below r ("lazy" form; the values pass of the PoseidonBN254
+// Merkle paths, coop.h bn_values): no unpacking, no packing, no conditional subtraction.  R = 2^261 leaves 7 bits above r (2^253.6):
+//   fr9_mont(a, b) = (a b + m r) / R < a b / R + r,
+// so the product of a value below 62 r (the worst the values pass forms: a state element after 56 lazy column updates) with a table constant
+// (< r) is below 1.4 r, and squares of anything below 6.2 r are below 1.3 r: every value stays below 2^261 without a single reduction
+// (the bounds are walked through at bn_values).  Limbs: t[0..7] < 2^29 after fr9_norm or fr9_mont ("normalised"), t[8] takes the rest.
+// A limb-wise sum of k normalised values has limbs below k 2^29: fr9_mont takes ONE operand with limbs below 2^30 (a sum of two) when the
+// other is normalised (column sums: 9 (2^30 2^29) + 9 2^58 + carry < 2^63); anything wider goes through fr9_norm first.
+struct fr9_t { uint32_t t[9]; };
+HD fr9_t fr9_from(const fr_t &A) {
+    const uint32_t MASK = (1u << 29) - 1; fr9_t a;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) {
+        const int lo = 29 * j, w = lo >> 6, sh = lo & 63;
+        uint64_t xa = A.l[w] >> sh;
+        if (sh > 35 && w < 3) xa |= A.l[w + 1] << (64 - sh);
+        a.t[j] = j < 8 ? ((uint32_t)xa & MASK) : (uint32_t)xa;
+    }
+    return a;
+}
+// normalised limbs of a value below 2^256 -> four 64-bit words (no reduction)
+HD fr_t fr9_pack(const fr9_t &a) {
+    const uint32_t *t = a.t; fr_t r;
+    r.l[0] = (uint64_t)t[0] | ((uint64_t)t[1] << 29) | ((uint64_t)t[2] << 58);
+    r.l[1] = ((uint64_t)t[2] >> 6) | ((uint64_t)t[3] << 23) | ((uint64_t)t[4] << 52);
+    r.l[2] = ((uint64_t)t[4] >> 12) | ((uint64_t)t[5] << 17) | ((uint64_t)t[6] << 46);
+    r.l[3] = ((uint64_t)t[6] >> 18) | ((uint64_t)t[7] << 11) | ((uint64_t)t[8] << 40);
+    return r;
+}
+HD fr9_t fr9_add(const fr9_t &a, const fr9_t &b) {
+    fr9_t r;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 9; i++) r.t[i] = a.t[i] + b.t[i];
+    return r;
+}
+HD fr9_t fr9_norm(const fr9_t &a) {
+    const uint32_t MASK = (1u << 29) - 1; fr9_t r; uint32_t c = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 8; i++) { const uint32_t v = a.t[i] + c; r.t[i] = v & MASK; c = v >> 29; }
+    r.t[8] = a.t[8] + c;
+    return r;
+}
+HD fr9_t fr9_mont(const fr9_t &A, const fr9_t &B, uint32_t ninv29) {
+    const uint32_t MASK = (1u << 29) - 1;
+    const uint32_t N[9] = {H2W_R29_0, H2W_R29_1, H2W_R29_2, H2W_R29_3, H2W_R29_4, H2W_R29_5, H2W_R29_6, H2W_R29_7, H2W_R29_8};
+    const uint32_t *a = A.t, *b = B.t; uint32_t m[9]; fr9_t r;
+    uint64_t acc = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 9; k++) {
+        uint64_t e = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i <= k; i++) { if (i & 1) e += (uint64_t)a[i] * b[k - i]; else acc += (uint64_t)a[i] * b[k - i]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i < k; i++) { if (i & 1) acc += (uint64_t)m[i] * N[k - i]; else e += (uint64_t)m[i] * N[k - i]; }
+        acc += e;
+        m[k] = ((uint32_t)acc * ninv29) & MASK;
+        acc += (uint64_t)m[k] * N[0];
+        acc >>= 29;
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 9; k < 17; k++) {
+        uint64_t e = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = k - 8; i < 9; i++) { if (i & 1) e += (uint64_t)a[i] * b[k - i]; else acc += (uint64_t)a[i] * b[k - i]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = k - 8; i < 9; i++) { if (i & 1) acc += (uint64_t)m[i] * N[k - i]; else e += (uint64_t)m[i] * N[k - i]; }
+        acc += e;
+        r.t[k - 9] = (uint32_t)acc & MASK; acc >>= 29;
+    }
+    r.t[8] = (uint32_t)acc;
+    return r;
+}
 // canonical a*b mod r (two Montgomery products)
 HD fr_t fr_mul(const fr_t &a, const fr_t &b, const FrParams &P) {
     if ((a.l[1] | a.l[2] | a.l[3] | b.l[1] | b.l[2] | b.l[3]) == 0) return fr_from_u128((u128)a.l[0] * b.l[0]);
