@@ -450,6 +450,20 @@ def main():
         if isol:
             dom = max((kk for kk in kernels if kk in kbytes), key=lambda kk: kernels[kk]["ms_isolated"])
             achieved = kernels[dom]["achieved_GBps"]
+        # HBM traffic of the dominant kernel per launch: PMC counters cannot be collected from inside this process; the rocprofv3 --pmc passes of the
+        # same launch (tools/collect_evidence.sh pmc: WRITE_SIZE and FETCH_SIZE in separate passes, units of 1 KiB; FETCH_SIZE doubled: gfx950
+        # counts a wide streaming read at half its bytes, MI355X_MICROARCH.md) are a committed file - used only for the workload they were taken on
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic_cfg3_bn254_b64.json")
+        if isol and args.config == "cfg3" and hash_mode == 1 and B == 64 and world == 1 and bps is None and args.lookup_bits == 21 and os.path.exists(pmc_file):
+            try:
+                pm = json.load(open(pmc_file))["merkle_path_passes_%d" % (passes_timed or 1)]
+                ent = next(v for k_, v in pm.items() if names[dom].split("<")[0] in k_)
+                traffic = ent["WRITE_SIZE"] * 1024 + 2 * ent["FETCH_SIZE"] * 1024
+                traffic_src = {"file": "profiles/r03_pmc_traffic_cfg3_bn254_b64.json", "WRITE_SIZE_KiB": ent["WRITE_SIZE"], "FETCH_SIZE_KiB": ent["FETCH_SIZE"],
+                               "what": "bytes per launch = (WRITE_SIZE + 2 x FETCH_SIZE) x 1024, rocprofv3 --pmc passes of tools/launch_timing.py --batch 64 (an earlier run of the same launch, not this process)"}
+            except Exception:
+                traffic, traffic_src = None, None
         out = {
             "metric": "FRI-verifier witness cells/sec", "value": value, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -473,14 +487,14 @@ def main():
             "kernel_ms_isolated_per_rank": per_rank,
             "expand_schedule_timed_region": schedule,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS if achieved else None),
-                         "traffic": None, "algorithmic_bytes": kbytes.get(dom), "kernel": names[dom], "kernels": kernels,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": kbytes.get(dom), "kernel": names[dom], "kernels": kernels,
                          "other_merkle_path_form": ({"merkle_path_passes": 2 if passes_timed == 1 else 1, "kernels": table(isol_other, None), "launch_ms_isolated": isol_other.get("launch")} if isol_other else None),
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS / world,
                          "expand_back_to_back_GBps": b2b_gbs, "expand_back_to_back_frac": (b2b_gbs / HBM_PEAK_GBS if b2b_gbs else None),
                          "note": "kernel = the advice-writing kernel with the largest ISOLATED duration among the kernels of the timed region; achieved = its algorithmic bytes (32 B x the cells it "
                                  f"writes per launch) / its duration, launched alone ({args.calib} launches after the timed region, one at a time, every kernel on one stream; HIP events recorded by the "
                                  "library on that stream). other_merkle_path_form: the same launch with the other setting of H2W_OPT_CHAIN_PASSES (not what the timed region ran). whole_job_frac = value x 32 B / "
-                                 "peak per GPU (all kernels, overlapped launches). traffic: PMC counters are not collected in this process (rocprofv3 --pmc passes of the same workload: profiles/r03_pmc_*)"},
+                                 "peak per GPU (all kernels, overlapped launches). traffic: HBM bytes of that kernel per launch from rocprofv3 --pmc passes of the same launch (traffic_source; null for workloads without such a file)"},
             "latency": latency, "secondary": secondary, "eager": eager,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU legs run at N = 1 only (rank 0's host)

@@ -758,9 +758,9 @@ template <bool COLS, int MODE> struct QuadSinkT {
                     if (l == 2) g_store_fr(sb + 2, fr9_pack(C_));
                     s0p = fr9_add(quad_bcast9<2>(C_), kc_.kc);                          // a sum of two: only ever multiplied by a constant
                     fr9_t incl = fr9_add_if(l == 0, fr9_sel(l < 2, C_, B_), kc_.kx);    // T0 + S_0 c, S_1 s_1, S_2 s_2, S_3 s_3
-                    incl = fr9_add_if(l >= 1, incl, quad_dpp9<0x90>(incl));
-                    incl = fr9_add_if(l >= 2, incl, quad_dpp9<0x44>(incl));
-                    S = fr9_norm(fr9_sel(l == 0, quad_bcast9<3>(incl), S));
+                    incl = fr9_add(incl, quad_dpp9<0xB1>(incl));                         // butterfly over the quad: every lane ends with the sum of the four
+                    incl = fr9_add(incl, quad_dpp9<0x4E>(incl));
+                    S = fr9_norm(fr9_sel(l == 0, incl, S));
                     kc_ = kn;
                 }
                 {   // the last round's column update
