@@ -1,0 +1,23 @@
+"""The lazy nine-limb Montgomery arithmetic of the values pass (csrc/field.h fr9_t), checked on the host against the canonical product:
+products of un-reduced representatives up to (and past) the sizes the pass forms, sums of two as operands, normalisation, canonicalisation.
+field.h compiles as plain C++; the GPU parity tests check the pass end to end, this pins its arithmetic and its bounds."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lazy_limb_products_agree_with_the_canonical_product(tmp_path):
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = os.path.join(str(tmp_path), "fr9_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "halo2-plonky2-verifier_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "fr9_check.cpp"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
+    bits = int(r.stdout.split("widest product:")[1].split()[0])
+    assert bits <= 261
