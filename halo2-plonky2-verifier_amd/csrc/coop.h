@@ -388,9 +388,10 @@ enum { BK_C = 0, BK_S = 88, BK_M = 88 + 392, BK_P = 88 + 392 + 16, BK_N = 88 + 3
 constexpr int BN_PERM_CELLS = 4032;                         // cells of one permutation (20 + 1,100 + 2,912), without the Context's one cached load_zero cell
 constexpr int BN_NSLOT = 20;                                 // value slots per quad (the widest layer, a full-round mix, stages 4 inputs + 16 partial sums)
 constexpr int BN_SLOT_SQ = 16 * 2;                           // 16-byte units per slot row: 16 quads x 32 B
-constexpr int BK_X = 2 * BK_T;                                // behind the two forms: S_0 c of every partial round, times R (the values pass, bn_values)
+constexpr int BK_XC = 2 * BK_T;                               // behind the two forms: S_0 c of every partial round (first entry of its sparse row times its round
+constexpr int BK_X = BK_XC + 56;                              // constant), canonical (the one-pass emitter, bnkc) and times R (the values pass, through s_bn_tab9)
 constexpr int BK_ALL = BK_X + 56;
-__shared__ sq16_t s_bn_tab[2 * BK_T * 2];                    // [form][entry][half]: 32.9 KB (the BK_X block is only read in limb form: s_bn_tab9)
+__shared__ sq16_t s_bn_tab[BK_X * 2];                        // [form][entry][half], then the BK_XC block: 34.7 KB
 __shared__ sq16_t s_bn_val[QUAD_WAVES * BN_NSLOT * BN_SLOT_SQ];   // [wavefront][slot][quad][half]: 10 KB per wavefront
 // host: the table a plan uploads (BatchArgs::bn_tab): canonical entries, then the same entries times R, each followed by 0 and 1
 inline void bn_table_build(const h2w_poseidon_consts_t &k, const FrParams &P, fr_t *tab /*[BK_ALL]*/) {
@@ -399,17 +400,23 @@ inline void bn_table_build(const h2w_poseidon_consts_t &k, const FrParams &P, fr
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { tab[BK_M + 4 * i + j] = k.bn_m[i][j]; tab[BK_P + 4 * i + j] = k.bn_p[i][j]; }
     tab[BK_ZERO] = fr_zero(); tab[BK_ONE] = fr_from_u64(1);
     for (int i = 0; i < BK_T; i++) tab[BK_T + i] = fr_mont_mul(tab[i], P.r2, P.ninv);
-    // S_0 c of partial round r (first entry of its sparse row times its round constant), times R
-    for (int r = 0; r < 56; r++) tab[BK_X + r] = fr_mont_mul(tab[BK_T + BK_S + 7 * r], tab[BK_T + BK_C + 20 + r], P.ninv);
+    for (int r = 0; r < 56; r++) {
+        tab[BK_X + r] = fr_mont_mul(tab[BK_T + BK_S + 7 * r], tab[BK_T + BK_C + 20 + r], P.ninv);
+        tab[BK_XC + r] = fr_mont_mul(tab[BK_X + r], fr_from_u64(1), P.ninv);
+    }
 }
 __device__ __forceinline__ void stage_bn_consts(const fr_t *tab, int tid, int nthreads) {
     const sq16_t *src = reinterpret_cast<const sq16_t *>(tab);
-    for (int i = tid; i < 2 * BK_T * 2; i += nthreads) { sq16_t v; v.x = H2W_GLOAD64(&src[i].x); v.y = H2W_GLOAD64(&src[i].y); s_bn_tab[i] = v; }
+    for (int i = tid; i < BK_X * 2; i += nthreads) { sq16_t v; v.x = H2W_GLOAD64(&src[i].x); v.y = H2W_GLOAD64(&src[i].y); s_bn_tab[i] = v; }
     __syncthreads();
 }
 __device__ __forceinline__ fr_t bnk(int which, int idx) {
     const sq16_t a = s_bn_tab[(which * BK_T + idx) * 2], b = s_bn_tab[(which * BK_T + idx) * 2 + 1];
     fr_t r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = b.x; r.l[3] = b.y; return r;
+}
+__device__ __forceinline__ fr_t bnkc(int r) {
+    const sq16_t a = s_bn_tab[(BK_XC + r) * 2], b = s_bn_tab[(BK_XC + r) * 2 + 1];
+    fr_t v; v.l[0] = a.x; v.l[1] = a.y; v.l[2] = b.x; v.l[3] = b.y; return v;
 }
 // The values pass (bn_values) works on nine-limb lazy values (field.h fr9_t): its own table, the times-R entries and the BK_X block in limb
 // form, 12 dwords per entry (9 used): 27 KB of LDS instead of s_bn_tab.
@@ -789,7 +796,8 @@ template <bool COLS, int MODE> struct QuadSinkT {
         bool zc = zc_ref;                      // by value: a reference would be re-read with a flat load (vmcnt(0)) at every mix
         const int l = l4; const uint64_t ninv = cfg.P.ninv; const fr_t r2 = cfg.P.r2;
         Em e; e.l = l;
-        e.val = s_bn_val + ((threadIdx.x >> 6) * BN_NSLOT * BN_SLOT_SQ) + ((threadIdx.x & 63) >> 2) * 2;
+        const int val_off = ((threadIdx.x >> 6) * BN_NSLOT * BN_SLOT_SQ) + ((threadIdx.x & 63) >> 2) * 2;
+        e.val = s_bn_val + val_off;
         e.tabh = s_bn_tab + (l & 1);
         e.cell0 = cell_off;
         e.gdst = reinterpret_cast<unsigned long long>(out + cc.map(cell_off)) + (unsigned long long)l * 16;
@@ -878,46 +886,53 @@ template <bool COLS, int MODE> struct QuadSinkT {
                         qc0 = qn0; qc1 = qn1;
                     }
                     { const fr_t q = g_load_fr(sb + 3 * (BN_PARTIAL_ROUNDS - 1)); round(BN_PARTIAL_ROUNDS - 1, q, std::true_type()); }
-                } else
+                } else {
+                    // One pass: FOUR wavefront-level Montgomery products per partial round (five until round 3): the row product S_0 s0' = S_0 (x^5 + c)
+                    // is formed as x^4 (s0 S_0) + S_0 c - XS = X S_0 beside the squaring of X, S_0 c from the table (bnkc) - so that it does not
+                    // wait for x^5, and the column update of round r - 1 (its last three cells) rides in round r's first product:
+                    //   1: lane 0  X = s0 R            | lanes k  U_k = S'_k s0' of round r - 1  ->  its nv_k = U_k + s_k, staged into the pending layer
+                    //   2: lane 0  X2 = X X            | lane 1   x2 = s0 X      | lane 2  XS = X S_0     | lane 3  S_3 s_3
+                    //   3: lane 0  x4 = x2 X2          | lane 1   S_1 s_1        | lane 2  S_2 s_2
+                    //   4: lane 0  T0 = x4 XS = S_0 x5 | lane 1   x5 = x4 X
+                    //   s0' = x5 + c;  running sums of the row: T0 + S_0 c, + S_1 s_1, + S_2 s_2, + S_3 s_3 (the new s0)
+                    fr_t s0p = fr_zero();
+                    const int lm = l > 0 ? l - 1 : 0;
 #pragma unroll 1
-                for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
-                    // Five wavefront-level Montgomery products per partial round: the lanes that have no S-box do their own work
-                    // inside the S-box's instruction stream.
-                    //   A: lane 0  X = s0 R          | lanes 1-3  S_j * s_j          (their terms of the sparse row; s_j is not touched by the S-box)
-                    //   B: lane 0  x2 = s0 X         | lane 1     X2 = X X
-                    //   C: lane 0  x4 = x2 X2 ;  D: lane 0  x5 = x4 X ;  then s0' = x5 + c
-                    //   E: lane 0  S_0 * s0'         | lanes 1-3  S'_k * s0'         (column update)
-                    const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, lm = l > 0 ? l - 1 : 0, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
-                    // the previous round's layer (still staged: this round's values are put after product D) leaves between the products
-                    const bool pend = !COLS && r > 0;
-                    const sq16_t *pA = e.tabh + (ix - (BN_WIDTH * 2 - 1)) * 2, *pB = e.tabh + (ic - 1) * 2;
-                    sq16_t t0[7], t1[7], t2[6], t3[6];
-                    const fr_t ksxm = bnk(1, ix + l);
-                    if (pend) part_load<0, 7, 52>(e, bn_map_partial, pA, pB, t0);
-                    const fr_t A_ = fr_mont_mul(s, fr_sel(l == 0, r2, ksxm), ninv);
-                    if (pend) { part_store<0, 7, 52>(e, t0); part_load<7, 14, 52>(e, bn_map_partial, pA, pB, t1); }
-                    const fr_t Xb = quad_bcast<0>(A_);
-                    const fr_t B_ = fr_mont_mul(fr_sel(l == 0, s, Xb), Xb, ninv);
-                    if (pend) { part_store<7, 14, 52>(e, t1); part_load<14, 20, 52>(e, bn_map_partial, pA, pB, t2); }
-                    const fr_t X2b = quad_bcast<1>(B_);
-                    const fr_t x4 = fr_mont_mul(B_, X2b, ninv);
-                    if (pend) { part_store<14, 20, 52>(e, t2); part_load<20, 26, 52>(e, bn_map_partial, pA, pB, t3); }
-                    const fr_t x5 = fr_mont_mul(x4, Xb, ninv);
-                    if (pend) { part_store<20, 26, 52>(e, t3); e.cell0 += 52; e.gdst += 52ull * 32; }
-                    const fr_t s0n = fr_add(x5, bnk(0, ic));
-                    put(e, l, s);                                        // slots 0-3: the state before the round
-                    put_if(e, l == 0, 4, B_); put_if(e, l == 0, 5, x4); put_if(e, l == 0, 6, x5); put_if(e, l == 0, 7, s0n);
-                    const fr_t s0 = quad_bcast<0>(s0n);
-                    const fr_t E_ = fr_mont_mul(s0, fr_sel(l == 0, ksxm, bnk(1, ix + BN_WIDTH + lm)), ninv);
-                    fr_t incl = fr_sel(l == 0, E_, A_);                        // S[j] * s_j, then the running sums over the quad
-                    { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
-                    { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
-                    put(e, 8 + l, incl);
-                    const fr_t nv = fr_add(E_, s);
-                    put_if(e, l > 0, 12 + lm, nv);
-                    const fr_t ns0 = quad_bcast<3>(incl);
-                    s = fr_sel(l > 0, nv, ns0);
-                    if (COLS || r == BN_PARTIAL_ROUNDS - 1) flush_layer<52>(e, bn_map_partial, e.tabh + ix * 2, e.tabh + ic * 2);
+                    for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
+                        const int ix = BK_S + (BN_WIDTH * 2 - 1) * r, ic = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + r;
+                        // the previous round's layer (still staged: this round's values are put after product 4) leaves between the products
+                        const bool pend = !COLS && r > 0;
+                        const sq16_t *pA = e.tabh + (ix - (BN_WIDTH * 2 - 1)) * 2, *pB = e.tabh + (ic - 1) * 2;
+                        sq16_t t0[7], t1[7], t2[6], t3[6];
+                        if (pend) part_load<0, 7, 52>(e, bn_map_partial, pA, pB, t0);
+                        const fr_t A_ = fr_mont_mul(fr_sel(l == 0, s, s0p), fr_sel(l == 0, r2, bnk(1, ix - (BN_WIDTH * 2 - 1) + BN_WIDTH + lm)), ninv);      // (round 0: s0p = 0, the entry read is in the table)
+                        if (r > 0) { const fr_t nv = fr_add(A_, s); put_if(e, l > 0, 12 + lm, nv); s = fr_sel(l > 0, nv, s); }
+                        if (COLS && r > 0) flush_layer<52>(e, bn_map_partial, pA, pB);
+                        if (pend) { part_store<0, 7, 52>(e, t0); part_load<7, 14, 52>(e, bn_map_partial, pA, pB, t1); }
+                        const fr_t Xb = quad_bcast<0>(A_), s0b = quad_bcast<0>(s);
+                        const fr_t B_ = fr_mont_mul(fr_sel(l == 1, s0b, fr_sel(l == 3, s, Xb)), fr_sel(l < 2, Xb, bnk(1, ix + (l == 2 ? 0 : l))), ninv);
+                        if (pend) { part_store<7, 14, 52>(e, t1); part_load<14, 20, 52>(e, bn_map_partial, pA, pB, t2); }
+                        const fr_t x2b = quad_bcast<1>(B_), XSb = quad_bcast<2>(B_);
+                        const fr_t C_ = fr_mont_mul(fr_sel(l == 0, x2b, s), fr_sel(l == 0, B_, bnk(1, ix + l)), ninv);
+                        if (pend) { part_store<14, 20, 52>(e, t2); part_load<20, 26, 52>(e, bn_map_partial, pA, pB, t3); }
+                        const fr_t D_ = fr_mont_mul(quad_bcast<0>(C_), fr_sel(l == 0, XSb, Xb), ninv);
+                        if (pend) { part_store<20, 26, 52>(e, t3); e.cell0 += 52; e.gdst += 52ull * 32; }
+                        const fr_t s0n = fr_add(quad_bcast<1>(D_), bnk(0, ic));
+                        put(e, l, s);                                        // slots 0-3: the state before the round
+                        put_if(e, l == 1, 4, B_); put_if(e, l == 0, 5, C_); put_if(e, l == 1, 6, D_); put_if(e, l == 0, 7, s0n);
+                        fr_t incl = fr_sel(l == 0, fr_add(D_, bnkc(r)), fr_sel(l == 3, B_, C_));      // S_0 s0', then S_j s_j: the running sums over the quad
+                        { const fr_t t = quad_up1(incl); if (l >= 1) incl = fr_add(incl, t); }
+                        { const fr_t t = quad_up2(incl); if (l >= 2) incl = fr_add(incl, t); }
+                        put(e, 8 + l, incl);
+                        s0p = s0n;
+                        s = fr_sel(l == 0, quad_bcast<3>(incl), s);
+                    }
+                    {   // the last round's column update, then its layer
+                        const fr_t U = fr_mont_mul(s0p, bnk(1, BK_S + (BN_WIDTH * 2 - 1) * (BN_PARTIAL_ROUNDS - 1) + BN_WIDTH + lm), ninv);
+                        const fr_t nv = fr_add(U, s); put_if(e, l > 0, 12 + lm, nv); s = fr_sel(l > 0, nv, s);
+                        const int ixl = BK_S + (BN_WIDTH * 2 - 1) * (BN_PARTIAL_ROUNDS - 1), icl = BK_C + (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS - 1;
+                        flush_layer<52>(e, bn_map_partial, e.tabh + ixl * 2, e.tabh + icl * 2);
+                    }
                 }
             }
             // full_rounds(is_first = half == 0) (:112-160): load_constant of M and P, then 4 x (x^5, [ark], mix)
@@ -925,6 +940,9 @@ template <bool COLS, int MODE> struct QuadSinkT {
 #pragma unroll 1
             for (int r = 0; r < BN_FULL_ROUNDS / 2; r++) {
                 const bool last = r == BN_FULL_ROUNDS / 2 - 1;
+                // (the layers' ~80 source addresses are loop invariants the compiler would hoist out of this loop and then spill - every reload
+                //  a drain of the store queue; an opaque offset per round keeps them base + immediate)
+                { int vo = val_off, ll = l; asm volatile("" : "+v"(vo), "+v"(ll)); e.val = s_bn_val + vo; e.tabh = s_bn_tab + (ll & 1); e.l = ll; }
                 exp5_all();
                 if (!(half == 1 && last)) ark(half == 0 ? (r + 1) * BN_WIDTH : (BN_FULL_ROUNDS / 2 + 1) * BN_WIDTH + BN_PARTIAL_ROUNDS + r * BN_WIDTH);
                 mix(half == 0 && last ? 1 : 0);
