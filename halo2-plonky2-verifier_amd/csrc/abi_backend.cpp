@@ -69,6 +69,7 @@ struct AbiBackend {
     Fr fr_mul(const Fr &a, const Fr &b) { Fr o; ck(h2w_mul(ctx, &a, &b, &o)); return o; }
     Fr fr_mul_add(const Fr &a, const Fr &b, const Fr &c) { Fr o; ck(h2w_mul_add(ctx, &a, &b, &c, &o)); return o; }
     Fr fr_select(const Fr &a, const Fr &b, const Bool &sel) { Fr o; ck(h2w_select(ctx, &a, &b, &sel, &o)); return o; }
+    const FriTab *fri_tab() const { return nullptr; }      // the eager driver computes the FRI gadgets' constants as the reference does
     template <class ColF> Fr fr_select_from_idx_fn(int n, ColF colf, const Gl &idx) {
         std::vector<Fr> col((size_t)n); for (int i = 0; i < n; i++) col[i] = colf(i);
         Fr o; ck(h2w_select_from_idx(ctx, col.data(), (size_t)n, &idx, &o)); return o;

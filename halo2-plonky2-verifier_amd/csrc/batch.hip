@@ -217,7 +217,7 @@ struct h2w_plan {
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
     PlanEqualities eqs;
-    fr_t *d_bn_tab = nullptr; uint32_t *d_bn_tab9 = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
+    fr_t *d_bn_tab = nullptr; uint32_t *d_bn_tab9 = nullptr; FriTab *d_fri = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
     StrandTable *d_st = nullptr;                      // device copy of st
     bool small_mds = false;                           // Goldilocks-Poseidon MDS entries are tiny (coop.h glp_small_mds)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
@@ -320,6 +320,11 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             H2W_HIP(hipMalloc((void **)&pl->d_bn_tab9, tab9.size() * sizeof(uint32_t)));
             H2W_HIP(hipMemcpy(pl->d_bn_tab9, tab9.data(), tab9.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
+        {   // the FRI gadgets' shape constants (valbackend.h FriTab): per-call host work in the reference, a table here
+            FriTab ft; fri_tab_build(ft, pl->shape.degree_bits + pl->shape.rate_bits);
+            H2W_HIP(hipMalloc((void **)&pl->d_fri, sizeof(FriTab)));
+            H2W_HIP(hipMemcpy(pl->d_fri, &ft, sizeof(FriTab), hipMemcpyHostToDevice));
+        }
         H2W_HIP(hipMalloc((void **)&pl->d_st, sizeof(StrandTable)));
         H2W_HIP(hipMemcpy(pl->d_st, &pl->st, sizeof(StrandTable), hipMemcpyHostToDevice));
         H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t)));
@@ -343,6 +348,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
     if (p->d_bn_tab9) (void)hipFree(p->d_bn_tab9);
+    if (p->d_fri) (void)hipFree(p->d_fri);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_st) (void)hipFree(p->d_st);
     if (p->d_ncells) (void)hipFree(p->d_ncells);
@@ -490,7 +496,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.recs = (rec_t *)(ws + wl.recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
     A.cbs = (DevCB *)(ws + wl.cbs); A.status = (uint32_t *)(ws + wl.status);
     A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
-    A.bn_tab = p->d_bn_tab; A.bn_tab9 = p->d_bn_tab9;
+    A.bn_tab = p->d_bn_tab; A.bn_tab9 = p->d_bn_tab9; A.fri = p->d_fri;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.n_cap_items = p->n_cap_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell; A.load_flag = (uint32_t *)(ws + wl.lflag);
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->d_st; A.P = p->P; A.nproofs = (int)n_proofs;
     A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p);

@@ -28,6 +28,7 @@ struct BatchArgs {
     const StrandTable *st; FrParams P;      // the shape's strand table, in device memory (a by-value copy in the kernel arguments is copied to every lane's stack as soon as it is indexed)
     int nproofs;
     const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
+    const FriTab *fri;              // the shape's FRI-gadget constants (valbackend.h FriTab)
     const uint32_t *bn_tab9;        // the times-R entries and the BK_X block in limb form (coop.h bn_table9_build): the values pass
     fr_t *unit_state;               // [nproofs][st.total_unit][4]: output state of every PoseidonBN254 permutation unit (values phase -> emission)
     fr_t *unit_sbox;                // [nproofs][st.total_unit][56][3]: canonical x^2, x^4, x^5 of its partial rounds' S-boxes
@@ -64,7 +65,7 @@ __device__ __forceinline__ fr_t *block_out(const BatchArgs &A, int p, int q) {
 
 __device__ __forceinline__ ValCfg make_cfg(const BatchArgs &A, int p) {
     ValCfg c; c.proof = A.proofs + (uint64_t)p * A.proof_words; c.mode = A.shape.hash_mode; c.L = A.shape.lookup_bits; c.P = A.P;
-    c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = A.st; c.split = true;
+    c.inv_pos = A.inv_pos; c.inv_neg = A.inv_neg; c.st = A.st; c.split = true; c.fri = A.fri;
     c.load_items = A.load_items; c.n_load_items = A.n_load_items; c.n_cap_items = A.n_cap_items; c.load_nrec = A.load_nrec; c.load_ncell = A.load_ncell;
     c.split_bn = false;
     return c;

@@ -15,6 +15,21 @@ namespace h2w {
 constexpr int SPONGE_WIDTH = 12, SPONGE_RATE = 8, HALF_N_FULL_ROUNDS = 4, N_PARTIAL_ROUNDS = 22, NUM_HASH_OUT_ELTS = 4;
 constexpr int BN_WIDTH = 4, BN_RATE = 3, BN_FULL_ROUNDS = 8, BN_PARTIAL_ROUNDS = 56;
 constexpr int MAX_STEPS = 8, MAX_ARITY = 16, MAX_CAP = 64, MAX_BATCH_POLYS = 16, MAX_FINAL_POLY = 128;      // MAX_CAP: cap_height <= 6 (sizes only the host-side / Goldilocks-caps indicator arrays)
+// Constants of the FRI gadgets that depend on the shape only (fri/mod.rs:222-322 recomputes them at every call: the two-adic subgroup of each
+// arity, its barycentric weights - an inversion each -, the inverse generator, the generator of the LDE domain).  Built once per plan on the host
+// (fri_tab_build); a backend without one (fri_tab() == nullptr: the eager ABI driver, the shape compiler's replay) computes them as the reference does.
+constexpr int FRI_TAB_BITS = 4;
+static_assert((1 << FRI_TAB_BITS) == MAX_ARITY, "FriTab is indexed by arity_bits <= log2 MAX_ARITY");
+struct FriTab { uint64_t dom[FRI_TAB_BITS + 1][MAX_ARITY], bw[FRI_TAB_BITS + 1][MAX_ARITY], g_inv[FRI_TAB_BITS + 1], root_lde; int64_t lde_bits; };
+inline void fri_tab_build(FriTab &t, int lde_bits) {
+    for (int ab = 0; ab <= FRI_TAB_BITS; ab++) {
+        const int n = 1 << ab; const uint64_t g = gl_primitive_root_of_unity(ab);
+        uint64_t *dom = t.dom[ab]; dom[0] = 1; for (int i = 1; i < n; i++) dom[i] = gl_mul(dom[i - 1], g);
+        for (int i = 0; i < MAX_ARITY; i++) { if (i >= n) { dom[i] = 0; t.bw[ab][i] = 0; continue; } uint64_t pr = 1; for (int j = 0; j < n; j++) if (j != i) pr = gl_mul(pr, gl_sub(dom[i], dom[j])); t.bw[ab][i] = gl_inv(pr); }
+        t.g_inv[ab] = gl_exp(g, (uint64_t)n - 1);
+    }
+    t.root_lde = gl_primitive_root_of_unity(lde_bits); t.lde_bits = lde_bits;
+}
 enum { PRE_NONE = 0, PRE_A = 1, PRE_B = 2 };
 
 // shape-derived quantities (plonky2 FriParams)

@@ -41,9 +41,14 @@ typedef unsigned __int128 u128;
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
 #define H2W_GLOAD64(p) (*(const ::h2w::gu64_t *)(p))
 #define H2W_GSTORE64(p, v) (*(::h2w::gu64_t *)(p) = (v))
+// a word of a table no kernel writes (constant address space): with a wavefront-uniform address it is a scalar load - outside the in-order
+// queue of the vector loads and stores, where a load waits for every record store issued before it
+typedef __attribute__((address_space(4))) const unsigned long long cu64_t;
+#define H2W_CLOAD64(p) (*(const ::h2w::cu64_t *)(p))
 #else
 #define H2W_GLOAD64(p) (*(const unsigned long long *)(p))
 #define H2W_GSTORE64(p, v) (*(unsigned long long *)(p) = (v))
+#define H2W_CLOAD64(p) (*(const unsigned long long *)(p))
 #endif
 typedef h2w_fr_t fr_t;
 

@@ -35,6 +35,7 @@ HF uint64_t strand_q_cell(const StrandTable &t, int q) { return q == 0 ? t.q_cel
 struct LoadItem { uint32_t word; uint32_t kind; uint64_t rec; uint64_t cell; };   // kind 0: GL load_witness, 1: GL 1-cell, 2: GL hash (4 const cells), 3: BN254 hash (1 cell), 4: limb decomposition of a BN254 cap hash (challenger/mod.rs:65-74)
 
 struct ValCfg {
+    const FriTab *fri = nullptr;     // device strands: the plan's table (device memory)
     const uint64_t *proof;           // this proof's flat words
     int mode, L;                     // hash mode, lookup bits
     FrParams P;
@@ -54,6 +55,7 @@ template <class Sink> struct ValBackend {
     static constexpr bool kBnUnits = Sink::kBnUnits;           // every PoseidonBN254 permutation of this backend is a unit handled by the sink
     static constexpr int kHashMode = Sink::kHashMode;          // >= 0: the only hash mode this backend is ever run with (-1: the shape's)
     HF int md() const { if constexpr (kHashMode >= 0) return kHashMode; else return cfg.mode; }
+    HF const FriTab *fri_tab() const { return cfg.fri; }
     Sink &sink; ValCfg cfg; bool zero_cached; uint32_t status; uint64_t unit_idx = 0;
     HF void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *k) { sink.coop_poseidon_permute(st, k); }
     HF void glp_note() { sink.glp_note(); }      // a Goldilocks-Poseidon permutation starts here (the shape compiler counts them)

@@ -221,13 +221,17 @@ template <class B> struct Verifier {
     HNI Ex interpolate_coset(Gl coset_shift, const Ex *values, int n, const Ex &evaluation_point) {   // :222-283
         int arity_bits = 0; while ((1 << arity_bits) < n) arity_bits++;
         Ex shifted = ext.scalar_div(evaluation_point, coset_shift);
-        uint64_t dom[MAX_ARITY]; const uint64_t g = gl_primitive_root_of_unity(arity_bits);
-        dom[0] = 1; for (int i = 1; i < n; i++) dom[i] = gl_mul(dom[i - 1], g);          // two_adic_subgroup
+        const FriTab *ft = be.fri_tab();                                                   // the shape's constants, when the backend has them tabulated
+        uint64_t dom[MAX_ARITY];
+        if (ft) { for (int i = 0; i < n; i++) dom[i] = H2W_CLOAD64(&ft->dom[arity_bits][i]); }
+        else { const uint64_t g = gl_primitive_root_of_unity(arity_bits); dom[0] = 1; for (int i = 1; i < n; i++) dom[i] = gl_mul(dom[i - 1], g); }      // two_adic_subgroup
         Ex domain[MAX_ARITY]; Gl bw[MAX_ARITY]; Ex wv[MAX_ARITY];
         for (int i = 0; i < n; i++) { gle_t e; e.c[0] = dom[i]; e.c[1] = 0; domain[i] = ext.load_constant(e); }
         for (int i = 0; i < n; i++) {                                                     // barycentric_weights
-            uint64_t pr = 1; for (int j = 0; j < n; j++) if (j != i) pr = gl_mul(pr, gl_sub(dom[i], dom[j]));
-            bw[i] = gl.load_constant(gl_inv(pr));
+            uint64_t w;
+            if (ft) w = H2W_CLOAD64(&ft->bw[arity_bits][i]);
+            else { uint64_t pr = 1; for (int j = 0; j < n; j++) if (j != i) pr = gl_mul(pr, gl_sub(dom[i], dom[j])); w = gl_inv(pr); }
+            bw[i] = gl.load_constant(w);
         }
         for (int i = 0; i < n; i++) wv[i] = ext.scalar_mul(values[i], bw[i]);
         Ex eval = ext.load_zero(), tpp = ext.load_one();
@@ -241,7 +245,8 @@ template <class B> struct Verifier {
     }
     HF Ex compute_evaluation(Gl x, const Bool *within_bits, int arity_bits, const Ex *evals_in, const Ex &beta) {  // :285-322
         const int arity = 1 << arity_bits;
-        const uint64_t g = gl_primitive_root_of_unity(arity_bits), g_inv = gl_exp(g, (uint64_t)arity - 1);
+        const FriTab *ft = be.fri_tab();
+        const uint64_t g_inv = ft ? H2W_CLOAD64(&ft->g_inv[arity_bits]) : gl_exp(gl_primitive_root_of_unity(arity_bits), (uint64_t)arity - 1);
         Ex evals[MAX_ARITY];
         for (int i = 0; i < arity; i++) { int r = 0; for (int b = 0; b < arity_bits; b++) if (i & (1 << b)) r |= 1 << (arity_bits - 1 - b); evals[r] = evals_in[i]; }
         Bool rev[8]; for (int i = 0; i < arity_bits; i++) rev[i] = within_bits[arity_bits - 1 - i];
@@ -261,7 +266,8 @@ template <class B> struct Verifier {
         {   // :379-389
             Gl g = gl.load_constant(7);
             Bool rev[64]; for (int i = 0; i < nb; i++) rev[i] = x_index_bits[nb - 1 - i];
-            Gl phi = gl.exp_from_bits_const_base(gl_primitive_root_of_unity(n_log), rev, nb);
+            const FriTab *ft = be.fri_tab();
+            Gl phi = gl.exp_from_bits_const_base(ft ? H2W_CLOAD64(&ft->root_lde) : gl_primitive_root_of_unity(n_log), rev, nb);
             subgroup_x = gl.mul(g, phi);
         }
         Ex old_eval = combine_initial(q, cb, subgroup_x);
