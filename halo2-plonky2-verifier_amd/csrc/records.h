@@ -27,15 +27,20 @@ HD void g_store_rec(rec_t *p, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
 // a cell i lives at (c << k) + (i - starts[c]) for the LAST column c with starts[c] <= i; a fix-up kernel repeats the boundary cells
 // in the previous column and zero-fills the unused rows.  starts == nullptr: flat layout.
 struct ColMap { const uint64_t *starts; uint32_t ncols, k; };
+struct ColRange { uint64_t lo, hi, delta; };
+// rare (once per column a strand enters): kept out of line - and OUT OF THE CURSOR: as a member function it took the cursor's address, which put
+// the cursor of every column-layout kernel on the stack (each of its reads a flat load behind the record stores)
+static HOL ColRange col_locate(const uint64_t *starts, uint32_t ncols, uint32_t k, uint64_t cell) {
+    uint32_t a = 0, b = ncols;                   // largest c with starts[c] <= cell
+    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (g_load_u64(starts + mid) <= cell) a = mid; else b = mid; }
+    ColRange r; r.lo = g_load_u64(starts + a); r.hi = a + 1 < ncols ? g_load_u64(starts + a + 1) : ~0ull;
+    r.delta = ((uint64_t)a << k) - r.lo;
+    return r;
+}
 struct ColCursor {
     ColMap m; uint64_t lo, hi; uint64_t delta;      // cells in [lo, hi) map to cell + delta (mod 2^64)
     HD void init(const ColMap &cm) { m = cm; lo = 0; hi = cm.starts ? 0 : ~0ull; delta = 0; }
-    HOL void locate(uint64_t cell) {      // rare (once per column a strand enters): kept out of line
-        uint32_t a = 0, b = m.ncols;                   // largest c with starts[c] <= cell
-        while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (g_load_u64(m.starts + mid) <= cell) a = mid; else b = mid; }
-        lo = g_load_u64(m.starts + a); hi = a + 1 < m.ncols ? g_load_u64(m.starts + a + 1) : ~0ull;
-        delta = ((uint64_t)a << m.k) - lo;
-    }
+    HD void locate(uint64_t cell) { const ColRange r = col_locate(m.starts, m.ncols, m.k, cell); lo = r.lo; hi = r.hi; delta = r.delta; }
     HD uint64_t map(uint64_t cell) { if (cell < lo || cell >= hi) locate(cell); return cell + delta; }
 };
 
