@@ -98,13 +98,23 @@ __device__ __forceinline__ uint64_t glz_add2(uint64_t a, uint64_t b) {     // an
 // returns its element of the output.  K: the constant block in LDS, M: the dense MDS rows (stage_glp_consts).
 __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64_t *M, int l, bool small) {
     const int lc = l < SPONGE_WIDTH ? l : SPONGE_WIDTH - 1, lm = lc > 0 ? lc - 1 : 0;
-    auto full_round = [&](int rc) {
-        x = glz_add(x, K[KO_ARC + SPONGE_WIDTH * rc + lc]);
+    // LDS reads are ~110 cycles each for a wavefront with nothing else to run, and a read that is used where it stands is waited for there (a third
+    // of this function's time: profiles/r03_pmc_values_b1_after.txt): this lane's row of the dense MDS matrix sits in registers for all eight full
+    // rounds (small entries: one dword each), and every round's table words are read a round ahead.
+    uint32_t mrow[SPONGE_WIDTH];
+    if (small) {
+#pragma unroll
+        for (int j = 0; j < SPONGE_WIDTH; j++) mrow[j] = (uint32_t)M[lc * SPONGE_WIDTH + j];
+    }
+    uint64_t arc_n = K[KO_ARC + lc];
+    auto full_round = [&](int rc, int rc_next) {
+        x = glz_add(x, arc_n);
+        arc_n = K[KO_ARC + SPONGE_WIDTH * rc_next + lc];
         { const uint64_t x2 = glz_mul(x, x), x3 = glz_mul(x2, x), x4 = glz_mul(x2, x2); x = glz_mul(x3, x4); }      // x^7
         if (small) {
             uint64_t lo = 0, hi = 0;
 #pragma unroll
-            for (int j = 0; j < SPONGE_WIDTH; j++) { const uint64_t sj = readlane64(x, j); const uint32_t m = (uint32_t)M[lc * SPONGE_WIDTH + j]; lo += (uint64_t)m * (uint32_t)sj; hi += (uint64_t)m * (uint32_t)(sj >> 32); }
+            for (int j = 0; j < SPONGE_WIDTH; j++) { const uint64_t sj = readlane64(x, j); const uint32_t m = mrow[j]; lo += (uint64_t)m * (uint32_t)sj; hi += (uint64_t)m * (uint32_t)(sj >> 32); }
             x = glz_reduce((u128)lo + ((u128)hi << 32));
         } else {
             uint64_t acc = 0;
@@ -114,7 +124,7 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
         }
     };
 #pragma unroll 1
-    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(i);
+    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(i, i + 1 < HALF_N_FULL_ROUNDS ? i + 1 : HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS);      // (the last one reads ahead for the second half)
     x = glz_add(x, K[KO_FIRST + lc]);                                                    // partial_first_constant_layer
     {   // mds_partial_layer_init: element 0 stays, element c >= 1 = sum_r init[r-1][c-1] s_r
         uint64_t res = 0;
@@ -123,18 +133,20 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
         x = l == 0 ? x : res;
     }
     const uint64_t m00 = K[KO_CIRC] + K[KO_DIAG];
+    uint64_t wh_n = K[KO_WHAT + lm], prc_n = K[KO_PRC], vs_n = K[KO_VS + lm];
 #pragma unroll 1
     for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
         // One instruction stream, two jobs per product: lane 0 walks its S-box (x^7 = x^3 x^4), the other lanes form their terms w_hat_i s_i of the
         // sparse row beside its first product; s0' = s0^7 + c; then lane 0: (circ0 + diag0) s0', lanes i: s_i + v_i s0' in one multiply-add
-        const uint64_t wh = K[KO_WHAT + r * 11 + lm];
+        const uint64_t wh = wh_n, prc = prc_n, vs = vs_n;
+        { const int rn = r + 1 < N_PARTIAL_ROUNDS ? r + 1 : r; wh_n = K[KO_WHAT + rn * 11 + lm]; prc_n = K[KO_PRC + rn]; vs_n = K[KO_VS + rn * 11 + lm]; }
         const uint64_t p1 = glz_mul(x, l == 0 ? x : wh);                                    // lane 0: s0^2 | lanes i: w_hat_i s_i
         // lane 0 finishes its S-box on its own lane (the others compute along, unused) and only s0' is broadcast: arithmetic on broadcast values is
         // moved to the scalar unit by the compiler, where a 64 x 64 product is ~35 instructions instead of ~20 - and every instruction of a
         // wavefront that has its SIMD to itself costs the same four cycles
         const uint64_t x3 = glz_mul(p1, x), x4 = glz_mul(p1, p1);
-        const uint64_t s0n = readlane64(glz_add(glz_mul(x3, x4), K[KO_PRC + r]), 0);
-        const uint64_t p2 = glz_muladd(l == 0 ? m00 : K[KO_VS + r * 11 + lm], s0n, l == 0 ? 0 : x);      // lane 0: m00 s0' | lanes i: the new s_i
+        const uint64_t s0n = readlane64(glz_add(glz_mul(x3, x4), prc), 0);
+        const uint64_t p2 = glz_muladd(l == 0 ? m00 : vs, s0n, l == 0 ? 0 : x);      // lane 0: m00 s0' | lanes i: the new s_i
         // d = m00 s0' + sum_i w_hat_i s_i: a row scan
         uint64_t term = l == 0 ? p2 : p1; if (l >= SPONGE_WIDTH) term = 0;
         term = glz_add2(term, row_shr64<1>(term)); term = glz_add2(term, row_shr64<2>(term));
@@ -143,7 +155,7 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
         x = l == 0 ? d : p2;
     }
 #pragma unroll 1
-    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + i);
+    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) { const int rc = HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + i; full_round(rc, i + 1 < HALF_N_FULL_ROUNDS ? rc + 1 : rc); }
     return x >= GL_P ? x - GL_P : x;
 }
 constexpr int GLP_LIST_WORDS = 1 + SPONGE_WIDTH;            // one listed permutation: {index of its first record, input state}
