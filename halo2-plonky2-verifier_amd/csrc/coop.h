@@ -134,7 +134,7 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
     }
     const uint64_t m00 = K[KO_CIRC] + K[KO_DIAG];
     uint64_t wh_n = K[KO_WHAT + lm], prc_n = K[KO_PRC], vs_n = K[KO_VS + lm];
-#pragma unroll 1
+#pragma unroll 11
     for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
         // One instruction stream, two jobs per product: lane 0 walks its S-box (x^7 = x^3 x^4), the other lanes form their terms w_hat_i s_i of the
         // sparse row beside its first product; s0' = s0^7 + c; then lane 0: (circ0 + diag0) s0', lanes i: s_i + v_i s0' in one multiply-add
@@ -222,9 +222,18 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
         glp_slot++;
         sx = glp_permute_lanes(sx, lk, lm, lane, small_mds);
-        const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
         nrec += GLP_RECS;
-        cell_off += 2 * HALF_N_FULL_ROUNDS * (12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA)) + 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
+        cell_off += perm_cell_count();
+    }
+    // cells of one permutation's records (a constant of the run: read from the template table once - a global load behind the list store above
+    // waited, every permutation, for that store to drain)
+    uint64_t perm_cells_ = 0;
+    __device__ __forceinline__ uint64_t perm_cell_count() {
+        if (perm_cells_ == 0) {
+            const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
+            perm_cells_ = 2 * HALF_N_FULL_ROUNDS * (12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA)) + 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
+        }
+        return perm_cells_;
     }
     __device__ __noinline__ uint64_t sponge_challenge() {                      // ChallengerChip::get_challenge (:92-108, :260-277)
         if (sp_in) {
@@ -249,9 +258,8 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
             x = glp_permute_lanes(x, lk, lm, lane, small_mds);
 #pragma unroll
             for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = readlane64(x, i);
-            const uint64_t nG = ncells[T_GLOP], nKA = ncells[T_KA_GLOP];
             nrec += GLP_RECS;
-            cell_off += 2 * HALF_N_FULL_ROUNDS * (12 * nKA + 48 * nG + 12 + 12 * (1 + 13 * nKA)) + 12 * nKA + 12 + 121 * nKA + (uint64_t)N_PARTIAL_ROUNDS * (4 * nG + nKA + nKA + 11 * nKA + 12 + 11 * nKA);
+            cell_off += perm_cell_count();
             return;
         }
         lds64_t *const K = lk, *const s_a = la, *const s_b = lb;      // (by value: one read of the sink object per call)
