@@ -767,7 +767,7 @@ template <bool COLS, int MODE> struct QuadSinkT {
                     return k;
                 };
                 RoundK kc_ = round_k(0);
-#pragma unroll 1
+#pragma unroll 2
                 for (int r = 0; r < BN_PARTIAL_ROUNDS; r++) {
                     //   1: lane 0  X2 = s0 s0         | lanes k  S'_k s0' of round r - 1 (its column update: s_k += ...)
                     //   2: lane 0  X4 = X2 X2         | lane 1   XA = s0 S_0             | lanes 2, 3  S_j s_j
