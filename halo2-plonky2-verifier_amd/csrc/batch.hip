@@ -149,20 +149,6 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(Ba
     if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
 }
 
-// values phase: four lanes per (owned unit, kind); blockIdx.y = kind slot
-__global__ __launch_bounds__(QUAD_BLOCK) void k_merkle_bn_values(BatchArgs A) {
-    typedef QuadSinkT<false, QUAD_VALUES> Sink; typedef ValBackend<Sink> QuadB;
-    stage_bn_consts9(A.bn_tab9, threadIdx.x, QUAD_BLOCK);    // (block-wide barrier inside: before any wavefront leaves)
-    const unsigned total = A.sh.n_own_units;
-    if (((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;      // a wavefront past the last strand
-    unsigned idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
-    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes)
-    int p, q; own_unit_at(A, idx, p, q);
-    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
-    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    Sink sink;
-    quad_strand<QuadB>(A, sink, p, q, kind);
-}
 // between the two passes: the S-box values of the owned units' partial rounds, as the values pass left them (times R), to the canonical
 // values the emission shows - one lane per value, 168 per permutation unit
 __global__ __launch_bounds__(256) void k_sbox_canon(BatchArgs A, uint32_t units_per_query) {
@@ -550,7 +536,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             p->passes_of[p->n_batches % h2w_plan::EV_RING] = passes;
             if (nunits && passes == 1) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_fused<true>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_fused<false>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
             if (nunits && passes != 1) {
-                hipLaunchKernelGGL(k_merkle_bn_values, sgrid, dim3(QUAD_BLOCK), 0, cstream, A);
+                launch_merkle_bn_values(A, sgrid, cstream);
                 const uint32_t upq = (uint32_t)(p->st.q_nunit[0] > p->st.q_nunit[1] ? p->st.q_nunit[0] : p->st.q_nunit[1]);
                 const uint64_t nval = (uint64_t)nunits * upq * (BN_PARTIAL_ROUNDS * 3);
                 if (nval) hipLaunchKernelGGL(k_sbox_canon, dim3((unsigned)((nval + 255) / 256)), dim3(256), 0, cstream, A, upq);

@@ -103,6 +103,7 @@ template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(c
 }
 void launch_glue_strands(const BatchArgs &A, hipStream_t stream);      // glue.hip
 void launch_merkle_bn_emit(const BatchArgs &A, dim3 grid, hipStream_t stream);      // glue.hip
+void launch_merkle_bn_values(const BatchArgs &A, dim3 grid, hipStream_t stream);    // glue.hip
 void launch_prologue_values(const BatchArgs &A, hipStream_t stream);   // glue.hip
 
 }  // namespace h2w

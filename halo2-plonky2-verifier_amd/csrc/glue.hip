@@ -71,6 +71,23 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR __at
     quad_strand<QuadB>(A, sink, p, q, kind);
 }
 
+// values phase of the two-pass paths: four lanes per (owned unit, kind); blockIdx.y = kind slot.  In this (flattened) unit: the walk between two
+// permutation units - selects, the state's constants, the index bits - is inlined instead of a chain of calls through a 1.3 KB stack frame
+__global__ __launch_bounds__(QUAD_BLOCK) __attribute__((flatten)) void k_merkle_bn_values(BatchArgs A) {
+    typedef QuadSinkT<false, QUAD_VALUES> Sink; typedef ValBackend<Sink> QuadB;
+    stage_bn_consts9(A.bn_tab9, threadIdx.x, QUAD_BLOCK);    // (block-wide barrier inside: before any wavefront leaves)
+    const unsigned total = A.sh.n_own_units;
+    if (((blockIdx.x * QUAD_BLOCK + (threadIdx.x & ~63u)) >> 2) >= total) return;      // a wavefront past the last strand
+    unsigned idx = (blockIdx.x * QUAD_BLOCK + threadIdx.x) >> 2;
+    if (idx >= total) idx = total - 1;                  // tail quads redo the last strand (identical bytes)
+    int p, q; own_unit_at(A, idx, p, q);
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    Sink sink;
+    quad_strand<QuadB>(A, sink, p, q, kind);
+}
+void launch_merkle_bn_values(const BatchArgs &A, dim3 grid, hipStream_t stream) { hipLaunchKernelGGL(k_merkle_bn_values, grid, dim3(QUAD_BLOCK), 0, stream, A); }
+
 void launch_merkle_bn_emit(const BatchArgs &A, dim3 grid, hipStream_t stream) {
     if (A.cm.starts) hipLaunchKernelGGL(k_merkle_bn_emit<true>, grid, dim3(QUAD_BLOCK), 0, stream, A);
     else hipLaunchKernelGGL(k_merkle_bn_emit<false>, grid, dim3(QUAD_BLOCK), 0, stream, A);

@@ -74,11 +74,11 @@ def test_chain_round_loops_have_no_scratch_or_flat_accesses(tmp_path):
     _clean(glue, a, b, "emission partial-round loop")
     waits = [int(m.group(1)) for l in glue[a:b + 1] for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)] if m]
     assert waits and min(waits) >= 30, f"a vector-memory wait in the emission loop drains the store queue: vmcnt {waits}"
-    # values kernel (k_merkle_bn_values): no scratch in its round loops either
-    lo, hi = _function(lines, "_ZN3h2w9QuadSinkTILb0ELi1EE9bn_values")
-    for c, d in _loops(lines, lo, hi):
-        if _count(lines, c, d, "v_mad_u64_u32") >= 400:
-            _clean(lines, c, d, "values-pass round loop")
+    # values kernel (k_merkle_bn_values, glue.hip too): no scratch in its round loops either
+    lo, hi = _function(glue, "_ZN3h2w9QuadSinkTILb0ELi1EE9bn_values")
+    for c, d in _loops(glue, lo, hi):
+        if _count(glue, c, d, "v_mad_u64_u32") >= 400:
+            _clean(glue, c, d, "values-pass round loop")
 
 
 def test_expand_fast_has_no_scratch(tmp_path):
