@@ -21,3 +21,14 @@ def test_lazy_limb_products_agree_with_the_canonical_product(tmp_path):
     assert "OK" in r.stdout
     bits = int(r.stdout.split("widest product:")[1].split()[0])
     assert bits <= 261
+
+
+def test_fri_constants_table_equals_the_per_call_formulas(tmp_path):
+    """chips.h FriTab (what h2w_plan_compile tabulates for the device strands) against the formulas the reference evaluates at every call."""
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = os.path.join(str(tmp_path), "fri_tab_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "halo2-plonky2-verifier_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "fri_tab_check.cpp"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
