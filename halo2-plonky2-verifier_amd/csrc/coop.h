@@ -573,6 +573,7 @@ template <bool COLS, int MODE> struct QuadSinkT {
         unsigned long long gdst;       // byte address of this lane's first 16-byte piece of the current layer
         uint64_t cell0;                // flat index of the layer's first cell
         int l;
+        ColPolicy<COLS> cc;            // column layout: the cursor, by value too (nothing in the flat layout)
     };
     static __device__ __forceinline__ void put(const Em &e, int slot, const fr_t &v) {
         sq16_t *q = e.val + slot * BN_SLOT_SQ; q[0] = sq16_t{v.l[0], v.l[1]}; q[1] = sq16_t{v.l[2], v.l[3]};
@@ -588,7 +589,7 @@ template <bool COLS, int MODE> struct QuadSinkT {
         constexpr int NP = (N + 1) / 2;
         const bool hiq = e.l >= 2;
         if constexpr (COLS) {
-            if (cc.hi - e.cell0 < (uint64_t)N || e.cell0 < cc.lo) { flush_layer_cols<N>(e, map, baseA, baseB); return; }
+            if (e.cc.hi - e.cell0 < (uint64_t)N || e.cell0 < e.cc.lo) { e = flush_layer_cols<N>(e, map, baseA, baseB); return; }
         }
 #pragma unroll
         for (int k0 = 0; k0 < NP; k0 += 4) {                         // four LDS reads in flight, then their stores
@@ -667,8 +668,9 @@ template <bool COLS, int MODE> struct QuadSinkT {
             if (w.has1) { H2W_GSTORE64(g + 128, t1[q - Q0].x); H2W_GSTORE64(g + 129, t1[q - Q0].y); }
         }
     }
-    // column-major layout, a layer that crosses into the next column (rare): per-cell addresses
-    template <int N, class MapFn> __device__ __noinline__ void flush_layer_cols(Em &e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
+    // column-major layout, a layer that crosses into the next column (rare): per-cell addresses.  The working set goes in and comes back BY VALUE:
+    // taken by reference, this one out-of-line call kept the emitter's whole working set on the stack in the column-layout kernels
+    template <int N, class MapFn> __device__ __noinline__ Em flush_layer_cols(Em e, MapFn map, const sq16_t *baseA, const sq16_t *baseB) {
         if constexpr (COLS) {
             const bool hiq = e.l >= 2;
             for (int k = 0; k < (N + 1) / 2; k++) {
@@ -677,14 +679,15 @@ template <bool COLS, int MODE> struct QuadSinkT {
                     // (the map is a compile-time function: evaluate it through a small switch-free loop over both candidates)
                     const sq16_t *pa = src_ptr_rt(e, map, 2 * k, baseA, baseB), *pb = (2 * k + 1 < N) ? src_ptr_rt(e, map, 2 * k + 1, baseA, baseB) : pa;
                     const sq16_t t = *(hiq ? pb : pa);
-                    const uint64_t a = cc.map(e.cell0 + (uint64_t)c);
+                    const uint64_t a = e.cc.map(e.cell0 + (uint64_t)c);
                     unsigned long long *g = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned long long>(out + a) + (unsigned long long)(e.l & 1) * 16);
                     H2W_GSTORE64(g, t.x); H2W_GSTORE64(g + 1, t.y);
                 }
             }
             e.cell0 += (uint64_t)N;
-            e.gdst = reinterpret_cast<unsigned long long>(out + cc.map(e.cell0)) + (unsigned long long)e.l * 16;
+            e.gdst = reinterpret_cast<unsigned long long>(out + e.cc.map(e.cell0)) + (unsigned long long)e.l * 16;
         }
+        return e;
     }
     template <class MapFn> static __device__ __forceinline__ const sq16_t *src_ptr_rt(const Em &e, MapFn map, int c, const sq16_t *baseA, const sq16_t *baseB) {
         const BnSrc s = map(c);
@@ -822,7 +825,8 @@ template <bool COLS, int MODE> struct QuadSinkT {
         e.val = s_bn_val + val_off;
         e.tabh = s_bn_tab + (l & 1);
         e.cell0 = cell_off;
-        e.gdst = reinterpret_cast<unsigned long long>(out + cc.map(cell_off)) + (unsigned long long)l * 16;
+        e.cc = cc;
+        e.gdst = reinterpret_cast<unsigned long long>(out + e.cc.map(cell_off)) + (unsigned long long)l * 16;
         fr_t s = fr_sel(l < 2, fr_sel(l == 0, st[0], st[1]), fr_sel(l == 2, st[2], st[3]));
         auto exp5_all = [&]() {                          // S-box on every lane
             const fr_t X = fr_mont_mul(s, r2, ninv);
@@ -971,7 +975,7 @@ template <bool COLS, int MODE> struct QuadSinkT {
             }
         }
         st[0] = quad_bcast<0>(s); st[1] = quad_bcast<1>(s); st[2] = quad_bcast<2>(s); st[3] = quad_bcast<3>(s);
-        cell_off = e.cell0; zc_ref = zc;
+        cell_off = e.cell0; zc_ref = zc; cc = e.cc;
     }
 };
 
