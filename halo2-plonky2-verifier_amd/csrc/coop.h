@@ -201,7 +201,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
     }
     // observe_cap (challenger/mod.rs:65-74): hash j of the cap on lane j; Goldilocks hashes are their 4 words, BN254 hashes 5 limbs of 56 bits
     // (HashWire::to_goldilocks_vec, hash/poseidon_bn254/hash.rs:31-43: decompose_le(56, 5) - its cells are k_prologue_load's)
-    __device__ __noinline__ bool sponge_observe_cap(const uint64_t *proof, uint64_t w0, int n, int mode, int L) {
+    __device__ __forceinline__ bool sponge_observe_cap(const uint64_t *proof, uint64_t w0, int n, int mode, int L) {      // (inlined, like sponge_challenge: an out-of-line member takes the sink's address, and a sink in memory pays a scratch round trip behind the record stores for every counter it bumps)
         const int per = mode == 0 ? 4 : 5;
         sp_out = 0; if (sp_in + per * n > CH_BUF) return false;
         for (int base = 0; base < n; base += 64) {
@@ -235,7 +235,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         }
         return perm_cells_;
     }
-    __device__ __noinline__ uint64_t sponge_challenge() {                      // ChallengerChip::get_challenge (:92-108, :260-277)
+    __device__ __forceinline__ uint64_t sponge_challenge() {                   // ChallengerChip::get_challenge (:92-108, :260-277)
         if (sp_in) {
             for (int off = 0; off < sp_in; off += SPONGE_RATE) {
                 const int len = sp_in - off < SPONGE_RATE ? sp_in - off : SPONGE_RATE;
