@@ -146,23 +146,23 @@ template <class B> struct Verifier {
         }
         for (int i = 0; i < s.num_challenges; i++) ch.get_challenge();                               // stark_alphas (:203)
         observe_cap(ch, pl.quotient_cap);
-        cb.zeta = ch.get_extension_challenge();                                                     // :206
+        const Ex zeta = ch.get_extension_challenge(); cb.zeta = zeta;                               // :206 (what the strand goes on to use is kept in locals: the block is device memory behind a generic reference - every read of it a flat load behind the record stores)
         const int nz = s.n_cols + s.n_perm_z + s.n_quotient, nzn = s.n_cols + s.n_perm_z;
         ch.observe_ext_words(nz, [&](int i) { return zeta_word(i); });                               // observe_openings (:208)
         ch.observe_ext_words(nzn, [&](int i) { return zeta_next_word(i); });
         // get_fri_challenges (:128-165)
-        cb.fri_alpha = ch.get_extension_challenge();
+        const Ex fri_alpha = ch.get_extension_challenge(); cb.fri_alpha = fri_alpha;
         for (int i = 0; i < d.n_steps; i++) { observe_cap(ch, pl.commit_caps + (uint64_t)i * d.cap_size * 4); cb.fri_betas[i] = ch.get_extension_challenge(); }
         ch.observe_ext_words(d.final_poly_len, [&](int i) { return pl.final_poly + 2ull * i; });
         ch.observe_element(be.proof_gl(pl.pow_witness));
-        cb.fri_pow_response = ch.get_challenge();
+        const Gl pow_response = ch.get_challenge(); cb.fri_pow_response = pow_response;
         for (int i = 0; i < s.num_queries; i++) cb.fri_query_indices[i] = ch.get_challenge();
         // verify_proof_with_challenges: fri_instance_info (stark/mod.rs:144-200): zeta_next = g * zeta
-        { gle_t gv; gv.c[0] = gl_primitive_root_of_unity(s.degree_bits); gv.c[1] = 0; Ex g = ext.load_constant(gv); cb.zeta_next = ext.mul(g, cb.zeta); }
+        { gle_t gv; gv.c[0] = gl_primitive_root_of_unity(s.degree_bits); gv.c[1] = 0; Ex g = ext.load_constant(gv); cb.zeta_next = ext.mul(g, zeta); }
         // FriChip::verify_fri_proof (fri/mod.rs:446-502): PoW (:130-145), from_os_and_alpha (:45-62)
-        be.range_check(cb.fri_pow_response, 64 - s.pow_bits);
-        cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { return proof_ext(zeta_word(i)); }, cb.fri_alpha);
-        cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { return proof_ext(zeta_next_word(i)); }, cb.fri_alpha);
+        be.range_check(pow_response, 64 - s.pow_bits);
+        cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { return proof_ext(zeta_word(i)); }, fri_alpha);
+        cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { return proof_ext(zeta_next_word(i)); }, fri_alpha);
     }
     // ---- merkle strand: kind < 3: initial oracle `kind`; kind >= 3: fold step kind-3.  bits/cap_index are wires of the query.
     HF uint64_t query_word(int q) const { return pl.queries + (uint64_t)q * pl.query_words; }

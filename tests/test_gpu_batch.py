@@ -151,7 +151,8 @@ def test_shape_edge_cases(h2w, h2w_api, oracle, consts, mode):
     """Shapes the reference supports but never tests: no permutation argument (2 oracles), cap_height 0 (verify_proof,
     merkle/mod.rs:104-115), other pow bits / arity / column counts, one query."""
     cases = [dict(d=6, q=2, n_perm_z=0), dict(d=6, q=1, cap=0), dict(d=8, q=2, rb=2, cap=2, arity_bits=2, final_poly_bits=3),
-             dict(d=6, q=2, pow_bits=10, n_cols=6, n_quotient=4, n_pis=1, num_challenges=3), dict(d=9, q=2, rb=3, cap=1, arity_bits=3)]
+             dict(d=6, q=2, pow_bits=10, n_cols=6, n_quotient=4, n_pis=1, num_challenges=3), dict(d=9, q=2, rb=3, cap=1, arity_bits=3),
+             dict(d=5, q=2, cap=1, arity_bits=1, final_poly_bits=2)]      # (arity 2: every size of the tabulated FRI constants, chips.h FriTab, is walked by some case)
     for kw in cases:
         status, outs, nc = run_custom(h2w, h2w_api, oracle, consts, [11, 12], mode=mode, **kw)
         assert status == [0, 0], (kw, status)
