@@ -489,7 +489,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     A.sh.n_own_units = (uint32_t)own_count(n_proofs * (uint64_t)p->shape.num_queries, sh.rank, sh.world);
     A.sh.n_own_proofs = (uint32_t)own_count(n_proofs, sh.rank, sh.world);
     hipStream_t cstream = stream;      // chain kernels' stream
-    if (p->fork_chains && p->shape.hash_mode == 1) {
+    if (p->fork_chains) {
         int k = 0; while (k < p->n_side && p->side_of[k] != stream) k++;
         if (k == p->n_side && p->n_side < h2w_plan::N_SIDE) {
             int lo_pri = 0, hi_pri = 0; (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);      // the chain is the longest dependent piece of a launch: let its blocks be placed first
@@ -551,16 +551,21 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
         }
         // 4. query glue strands (FriChip::verify_query_round minus its Merkle proofs): one lane per owned (proof, query);
         //    Goldilocks-Poseidon Merkle strands (hash_mode 0), values: one cooperating wavefront per (proof, query, tree)
+        //    The two read the challenge blocks and write disjoint records (and list entries): with Goldilocks caps the Merkle strands run on the
+        //    plan's side stream beside the glue strands and rejoin before the permutations' records are emitted.
         H2W_HIP(hipEventRecord(ev[7], stream));
-        if (nunits) {
-            launch_glue_strands(A, stream);
-            if (p->shape.hash_mode == 0) {
-                if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_values<true>, dim3(nunits, nkinds), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_merkle_gl_values<false>, dim3(nunits, nkinds), dim3(64), 0, stream, A);
-            }
+        if (p->shape.hash_mode == 0) {
+            if (cstream != stream) { H2W_HIP(hipStreamWaitEvent(cstream, ev[9], 0)); forked = true; }
+            H2W_HIP(hipEventRecord(ev[4], cstream));
+            if (nunits) { if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_values<true>, dim3(nunits, nkinds), dim3(64), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_gl_values<false>, dim3(nunits, nkinds), dim3(64), 0, cstream, A); }
+            H2W_HIP(hipEventRecord(ev[10], cstream)); H2W_HIP(hipEventRecord(ev[5], cstream));
         }
-        if (p->shape.hash_mode == 0) { if (glp_emit(n_pro_perms + n_mk_perms) != 0) return -1; }
+        if (nunits) launch_glue_strands(A, stream);
+        if (p->shape.hash_mode == 0) {
+            if (forked) { H2W_HIP(hipStreamWaitEvent(stream, ev[5], 0)); forked = false; }
+            if (glp_emit(n_pro_perms + n_mk_perms) != 0) return -1;
+        }
         H2W_HIP(hipEventRecord(ev[2], stream));
-        if (p->shape.hash_mode == 0) { H2W_HIP(hipEventRecord(ev[4], stream)); H2W_HIP(hipEventRecord(ev[10], stream)); H2W_HIP(hipEventRecord(ev[5], stream)); }
         // 5. expansion of the block records (HBM-write-bound)
         ExpandArgs E;
         E.meta = p->d_meta; E.recs = A.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = A.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
