@@ -15,8 +15,12 @@ N > 1 (`--gpus N`; launched by torch.distributed.run, or spawned by this script 
 per GPU; rank 0 builds the proofs and ONE broadcast moves the proof block over RCCL (the only collective).
   * default: every rank generates the witnesses of its own shard of proofs ("weak" scaling: per-GPU work fixed);
   * `--shard-queries` (default for cfg5, BASELINE configs[4]): all ranks hold the same proofs and rank r generates the
-    (proof, query) units u with u % N == r plus the prologue blocks of the proofs it owns (h2w_fri_witness_batch_shard);
-    total work is fixed ("strong" scaling).
+    (proof, query) units u with u % N == r plus the prologue blocks of the proofs it owns (h2w_fri_witness_batch_shard_compact);
+    a launch covers `--batch` x N proofs, so that a rank's launch has as many units - and writes as many bytes - as an unsharded
+    launch of `--batch` proofs (a rank's packed buffers are 1 / N of the stream: it fits); total work is fixed ("strong" scaling).
+  * `--emulate-rank R --world W` (N = 1): ONE process on ONE GPU runs exactly what rank R of W would run in that mode (the broadcast
+    skipped: the proofs are generated in place), pipelined as usual, and reports that rank's own cells/s.  The path has no data-path
+    collective, so this IS the per-GPU rate of a W-GPU run.
 value = cells of all ranks / max-rank time.
 
 The CPU oracle (oracle/) is imported by the `cpu_baseline` leg only (rank 0, N = 1), never by the measured path.
@@ -44,6 +48,7 @@ CONFIGS = {
     "cfg5": (20, 84, 1, "2^20-row Fibonacci STARK, 84 FRI queries, rate_bits=1, cap_height=4"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 4   # wave64 VALU instructions the chip can issue per second: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per instruction = 6.1e11
 OPT_FORK_CHAINS = 1     # include/h2w.h H2W_OPT_FORK_CHAINS
 OPT_SERIAL_EXPAND = 2   # include/h2w.h H2W_OPT_SERIAL_EXPAND
 OPT_CHAIN_PASSES = 3    # include/h2w.h H2W_OPT_CHAIN_PASSES
@@ -115,6 +120,17 @@ def _cpu_worker(spec):
     print(json.dumps({"cells": r["_cells"], "proofs": r["_proofs"], "seconds": r["_seconds"]}))
 
 
+def kernel_source_sha16():
+    """sha256 over the kernel sources the library is built from (csrc/*.h, *.hip, *.cpp): committed PMC evidence names the sources it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "halo2-plonky2-verifier_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _spawn_ranks(n):
     """`--gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE anything touches the GPU here, relay rank 0's
     line, exit with the worst rank's code."""
@@ -124,6 +140,7 @@ def _spawn_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0 = procs[0].communicate()[0]
@@ -133,6 +150,27 @@ def _spawn_ranks(n):
 
 
 def main():
+    """A rank that dies leaves its traceback in a per-rank log file (an unattended multi-GPU run shows only rank 0's stdout)."""
+    try:
+        return _main()
+    except BaseException as e:
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+        rank = os.environ.get("RANK", "0")
+        logdir = os.environ.get("H2W_BENCH_LOG_DIR", os.path.join(ROOT, "gpurun_out"))
+        try:
+            os.makedirs(logdir, exist_ok=True)
+            with open(os.path.join(logdir, f"bench_rank{rank}.log"), "a") as f:
+                f.write(f"---- {time.strftime('%Y-%m-%d %H:%M:%S')} argv={sys.argv[1:]} WORLD_SIZE={os.environ.get('WORLD_SIZE')}\n")
+                traceback.print_exc(file=f)
+        except OSError:
+            pass
+        sys.stderr.write(f"[bench.py rank {rank}] failed: {e!r}\n")
+        raise
+
+
+def _main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(sys.argv[2])
     ap = argparse.ArgumentParser()
@@ -160,6 +198,9 @@ def main():
     ap.add_argument("--chain-passes", type=int, default=0, choices=[0, 1, 2], help="H2W_OPT_CHAIN_PASSES (0: the library's default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsing the N>1 logic on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="N = 1: run what rank R of --world ranks runs in the (proof, query)-sharded mode, on this one GPU, and report that rank's own rate")
+    ap.add_argument("--world", type=int, default=0, help="--emulate-rank: the world being emulated (default 8)")
+    ap.add_argument("--gen-budget-s", type=float, default=300.0, help="rank 0 stops generating valid proofs after this many seconds and repeats the ones it has (the other ranks wait in the broadcast)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return _spawn_ranks(args.gpus)          # (nothing has touched the GPU yet)
@@ -186,7 +227,13 @@ def main():
 
     d, q, rb, desc = CONFIGS[args.config]
     hash_mode = 1 if args.hash == "bn254" else 0
-    shard_queries = (args.shard_queries or args.config == "cfg5") and world > 1
+    emulate = args.emulate_rank >= 0
+    if emulate:
+        assert world == 1, "--emulate-rank is a single-process mode"
+        args.world = args.world or 8
+        assert 0 <= args.emulate_rank < args.world
+    shard_queries = ((args.shard_queries or args.config == "cfg5") and world > 1) or emulate
+    sh_rank, sh_world = (args.emulate_rank, args.world) if emulate else (rank, world)      # the sharding a launch runs with
     if shard_queries and not args.flat_shards:
         args.compact = True          # a rank's buffers hold its own blocks only: 1 / world of the stream, so world x the launches fit in flight
     shape = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=hash_mode, lookup_bits=args.lookup_bits)
@@ -210,20 +257,30 @@ def main():
     B = args.batch if args.batch > 0 else max(1, min(64, int(58.6e9 // cell_bytes)))
     S = max(1, args.streams)
     if shard_queries and args.compact:
-        S = min(S * min(world, 4), 16)      # a sharded launch is short (1 / world of the bytes behind the same serial strands): more of them in flight
+        # A sharded rank must be bound by its work, not by the serial strands of a launch (VERDICT r03 task 1): a launch covers B x world proofs, so
+        # the rank's (proof, query) units and bytes per launch are those of an unsharded launch of B proofs - its packed buffers are 1 / world of
+        # the stream, so it fits.  (Round 3 kept B and raised the launches in flight instead: every kernel but the expansion ran at its serial floor.)
+        B = min(B * sh_world, 65535)
     if args.share_gpu0:
         args.advice_cap_gb /= world
-    free_b, _total_b = torch.cuda.mem_get_info(dev)         # leave 16 GB for the workspaces, the proofs and the allocator
-    args.advice_cap_gb = min(args.advice_cap_gb, (free_b / (world if args.share_gpu0 else 1) - 16e9) / 1e9)
-    per_launch = B * cell_bytes / (world if (shard_queries and args.compact) else 1)
-    while S > 1 and S * per_launch > args.advice_cap_gb * 1e9:   # stay inside the 288 GB of HBM
+    free_b, _total_b = torch.cuda.mem_get_info(dev)         # leave 8 GB for the proofs and the allocator
+    args.advice_cap_gb = min(args.advice_cap_gb, (free_b / (world if args.share_gpu0 else 1) - 8e9) / 1e9)
+
+    def launch_bytes(b):
+        adv = plan.shard_cells(b, sh_rank, sh_world) * 32 if (shard_queries and args.compact) else b * cell_bytes
+        return adv + (plan.shard_workspace_bytes(b, sh_rank, sh_world) if shard_queries else plan.workspace_bytes(b))
+    while S > 3 and S * launch_bytes(B) > args.advice_cap_gb * 1e9:      # stay inside the 288 GB of HBM: fewer launches in flight ...
+        S -= 1
+    while B > sh_world and S * launch_bytes(B) > args.advice_cap_gb * 1e9:      # ... then smaller ones
+        B -= sh_world if shard_queries else 1
+    while S > 1 and S * launch_bytes(B) > args.advice_cap_gb * 1e9:
         S -= 1
     R = max(args.launches_per_step, 1)
     total_proofs = B if shard_queries else B * world      # distinct proofs resident per step (every launch of a rank re-uses its B proofs)
 
     # ---- inputs: rank 0 synthesises all proofs, one RCCL broadcast moves the proof block
     words = plan.proof_words
-    gen_seconds = None
+    gen_seconds = n_generated = None
     if args.proofs == "valid" and args.backend != "gloo":
         # valid FRI instances (SURVEY 8d variant (A)): random committed polynomials, proved on the ingest rank's GPU in lockstep batches;
         # the proofs never visit the host.
@@ -234,11 +291,18 @@ def main():
             assert pr.proof_words == words
             gen = torch.Generator(device=dev); gen.manual_seed(0xF1B00000)
             chunk = max(1, min(total_proofs, (8 << 21) >> (d + rb)))              # ~5 GB of prover scratch at a time
+            n_generated = total_proofs
             for first in range(0, total_proofs, chunk):
+                if first and time.perf_counter() - t_gen > args.gen_budget_s:      # the other ranks are waiting in the broadcast: repeat what there is
+                    n_generated = first
+                    for at in range(first, total_proofs, first):
+                        nb = min(first, total_proofs - at)
+                        all_proofs[at * words:(at + nb) * words] = all_proofs[:nb * words]
+                    break
                 nb = min(chunk, total_proofs - first)
                 coefs = torch.randint(0, 1 << 62, (nb * pr.num_polys << d,), dtype=torch.int64, device=dev, generator=gen)   # < 2^62 < p: canonical
                 pr.prove_batch(coefs.data_ptr(), [1, 1, 2] * nb, all_proofs[first * words:].data_ptr(), nb, torch.cuda.current_stream(dev).cuda_stream)
-            torch.cuda.synchronize(dev)
+                torch.cuda.synchronize(dev)
             gen_seconds = time.perf_counter() - t_gen
             pr.close(); del coefs
             torch.cuda.empty_cache()
@@ -261,9 +325,9 @@ def main():
         assert hi - lo == B
         my_proofs = all_proofs[lo * words:hi * words]
 
-    adv_bytes = plan.shard_cells(B, rank, world) * 32 if (shard_queries and args.compact) else B * cell_bytes
+    adv_bytes = plan.shard_cells(B, sh_rank, sh_world) * 32 if (shard_queries and args.compact) else B * cell_bytes
     advices = [torch.empty(adv_bytes, dtype=torch.uint8, device=dev) for _ in range(S)]
-    wss = [torch.empty(plan.workspace_bytes(B), dtype=torch.uint8, device=dev) for _ in range(S)]
+    wss = [torch.empty(plan.shard_workspace_bytes(B, sh_rank, sh_world) if shard_queries else plan.workspace_bytes(B), dtype=torch.uint8, device=dev) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     torch.cuda.synchronize()
     counter = [0]
@@ -274,7 +338,7 @@ def main():
         if bps is not None:
             plan.run_columns(my_proofs.data_ptr(), B, bps, args.k, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
         elif shard_queries:
-            (plan.run_shard_compact if args.compact else plan.run_shard)(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), rank, world, streams[i].cuda_stream)
+            (plan.run_shard_compact if args.compact else plan.run_shard)(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), sh_rank, sh_world, streams[i].cuda_stream)
         else:
             plan.run(my_proofs.data_ptr(), B, advices[i].data_ptr(), wss[i].data_ptr(), streams[i].cuda_stream)
 
@@ -372,6 +436,11 @@ def main():
     if args.calib > 0 and world == 1 and not args.no_extras and bps is None:
         latency = {("%s_%s_batch1_ms" % (args.config, args.hash)): one_proof_ms(plan, my_proofs.data_ptr(), advices[0], wss[0]),
                    "what": "wall time of one h2w_fri_witness_batch call on a single proof, enqueue to completion on an idle GPU (median of 10)"}
+    n_ranks_seen = 1
+    if world > 1:      # how many ranks the collective library itself saw: a sum of ones over RCCL (gloo in rehearsals)
+        ones = torch.ones(1, dtype=torch.int64, device=torch.device("cpu") if args.backend == "gloo" else dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        n_ranks_seen = int(ones.item())
     per_rank = None
     if world > 1 and isol:
         gathered = [None] * world
@@ -380,28 +449,45 @@ def main():
 
     # ---- secondary legs (N = 1): the same shape with Goldilocks-Poseidon caps; the level-1 (eager NativeChip) boundary
     secondary = eager = None
-    if world == 1 and not args.no_extras and args.config == "cfg3" and hash_mode == 1 and bps is None:
+    if world == 1 and not emulate and not args.no_extras and args.config == "cfg3" and hash_mode == 1 and bps is None:
         for t in advices + wss:
             del t
         advices.clear(); wss.clear()
         torch.cuda.empty_cache()
         gshape = h2w.fibonacci_shape(d, q, rate_bits=rb, hash_mode=0, lookup_bits=args.lookup_bits)
         gplan = api.Plan(gshape, consts, local_rank)
-        gB = max(1, int(58.6e9 // (gplan.num_cells * 32))); gS = 3
+        gB = max(1, int(58.6e9 // (gplan.num_cells * 32))); gS = max(1, args.streams)      # the primary's schedule: the same bytes per launch, the same launches in flight
         prng = np.random.default_rng(0xF1B00003)
         gproofs = torch.from_numpy(prng.integers(0, 1 << 60, gB * gplan.proof_words, dtype=np.int64)).to(dev)
         gadv = [torch.empty(gB * gplan.num_cells * 32, dtype=torch.uint8, device=dev) for _ in range(gS)]
         gws = [torch.empty(gplan.workspace_bytes(gB), dtype=torch.uint8, device=dev) for _ in range(gS)]
 
+        while len(streams) < gS:
+            streams.append(torch.cuda.Stream(device=dev))
+
         def glaunches(n):
             for j in range(n):
                 gplan.run(gproofs.data_ptr(), gB, gadv[j % gS].data_ptr(), gws[j % gS].data_ptr(), streams[j % gS].cuda_stream)
-        glaunches(2 * gS); torch.cuda.synchronize()
-        nl = 24
+        glaunches(3 * gS); torch.cuda.synchronize()      # three full rounds over the streams before the clock starts
+        nl = 96
         t1 = time.perf_counter(); glaunches(nl); torch.cuda.synchronize(); gt = time.perf_counter() - t1
+        # its dominant kernel alone (HIP events of the library on the launch stream, as for the primary): the expansion kernel
+        gplan.configure(OPT_FORK_CHAINS, 0)
+        grows = []
+        for _ in range(args.calib + 1):
+            torch.cuda.synchronize(); gplan.run(gproofs.data_ptr(), gB, gadv[0].data_ptr(), gws[0].data_ptr(), streams[0].cuda_stream); torch.cuda.synchronize()
+            grows.append(gplan.timing_ex(0))
+        gplan.configure(OPT_FORK_CHAINS, 1)
+        g_ms = {kk: sum(r_[i] for r_ in grows[1:]) / len(grows[1:]) for i, kk in enumerate(("prologue_values", "perm_records", "glue_and_merkle_strands", None, None, "expand", "launch")) if kk}
+        g_bytes = gB * gplan.num_record_cells * 32
         secondary = {"workload": f"{args.config} with Goldilocks-Poseidon Merkle caps ({gplan.num_cells} cells = {gplan.num_cells * 32 / 1e9:.1f} GB per proof), uniform random proof words",
                      "value": gplan.num_cells * gB * nl / gt, "unit": "cells/s", "proofs_per_launch": gB, "launches": nl, "launches_in_flight": gS, "seconds": gt,
-                     "frac_of_hbm_peak": gplan.num_cells * gB * nl * 32 / gt / 1e9 / HBM_PEAK_GBS}
+                     "frac_of_hbm_peak": gplan.num_cells * gB * nl * 32 / gt / 1e9 / HBM_PEAK_GBS,
+                     "kernel_ms_isolated": g_ms,
+                     "roofline": {"bound": "hbm", "kernel": "expand_fast<%d, true>" % args.lookup_bits, "algorithmic_bytes": g_bytes, "achieved": g_bytes / (g_ms["expand"] * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_bytes / (g_ms["expand"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "32 B x the cells the expansion kernel writes per launch / its duration launched alone (the other kernels of this mode write records, not advice)"},
+                     "same_as_primary_with": "--hash gl"}
         if latency is not None:
             latency[f"{args.config}_gl_batch1_ms"] = one_proof_ms(gplan, gproofs.data_ptr(), gadv[0], gws[0])
         del gadv, gws
@@ -423,9 +509,13 @@ def main():
     if rank == 0:
         launches = args.steps * R
         total_cells = plan.num_cells * B * launches * (1 if shard_queries else world)
+        if emulate:      # the cells rank sh_rank of sh_world writes: its prologue blocks and its (proof, query) blocks (h2w_plan_shard_block)
+            lay = plan.strand_layout()
+            own = D.shard_cells(B, q, sh_rank, sh_world, lay[0], lay[1], lay[2])
+            total_cells = own * launches
         value = total_cells / elapsed
         # roofline of the kernel with the largest isolated duration among the kernels that write the advice (32 B per cell)
-        share = (1.0 / world) if shard_queries else 1.0      # a rank's share of the cells of a launch
+        share = (1.0 / sh_world) if shard_queries else 1.0      # a rank's share of the cells of a launch
         kbytes = {"expand": B * plan.num_record_cells * 32 * share}
         if hash_mode == 1:
             kbytes["chain_emit"] = kbytes["merkle_chains"] = B * plan.num_chain_cells * 32 * share
@@ -453,20 +543,33 @@ def main():
         # HBM traffic of the dominant kernel per launch: PMC counters cannot be collected from inside this process; the rocprofv3 --pmc passes of the
         # same launch (tools/collect_evidence.sh pmc: WRITE_SIZE and FETCH_SIZE in separate passes, units of 1 KiB; FETCH_SIZE doubled: gfx950
         # counts a wide streaming read at half its bytes, MI355X_MICROARCH.md) are a committed file - used only for the workload they were taken on
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic_cfg3_bn254_b64.json")
-        if isol and args.config == "cfg3" and hash_mode == 1 and B == 64 and world == 1 and bps is None and args.lookup_bits == 21 and os.path.exists(pmc_file):
-            try:
-                pm = json.load(open(pmc_file))["merkle_path_passes_%d" % (passes_timed or 1)]
-                ent = next(v for k_, v in pm.items() if names[dom].split("<")[0] in k_)
-                traffic = ent["WRITE_SIZE"] * 1024 + 2 * ent["FETCH_SIZE"] * 1024
-                traffic_src = {"file": "profiles/r03_pmc_traffic_cfg3_bn254_b64.json", "WRITE_SIZE_KiB": ent["WRITE_SIZE"], "FETCH_SIZE_KiB": ent["FETCH_SIZE"],
-                               "what": "bytes per launch = (WRITE_SIZE + 2 x FETCH_SIZE) x 1024, rocprofv3 --pmc passes of tools/launch_timing.py --batch 64 (an earlier run of the same launch, not this process)"}
-            except Exception:
-                traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r04_pmc_cfg3_bn254_b64.json")
+        src_sha = kernel_source_sha16()
+        if isol and args.config == "cfg3" and hash_mode == 1 and B == 64 and world == 1 and not shard_queries and bps is None and args.lookup_bits == 21:
+            if not os.path.exists(pmc_file):
+                traffic_src = {"file": None, "why_null": "no committed PMC pass for this workload"}
+            else:
+                try:
+                    pmj = json.load(open(pmc_file))
+                    if pmj.get("kernel_source_sha16") != src_sha:
+                        traffic_src = {"file": "profiles/r04_pmc_cfg3_bn254_b64.json", "why_null": f"the PMC passes were taken on kernel sources {pmj.get('kernel_source_sha16')} (commit {pmj.get('commit')}), this run is {src_sha}: stale, not reported"}
+                    else:
+                        ent = next(v for k_, v in pmj["merkle_path_passes_%d" % (passes_timed or 1)].items() if names[dom].split("<")[0] in k_)
+                        traffic = ent["WRITE_SIZE"] * 1024 + 2 * ent["FETCH_SIZE"] * 1024
+                        traffic_src = {"file": "profiles/r04_pmc_cfg3_bn254_b64.json", "commit": pmj.get("commit"), "kernel_source_sha16": src_sha, "WRITE_SIZE_KiB": ent["WRITE_SIZE"], "FETCH_SIZE_KiB": ent["FETCH_SIZE"],
+                                       "unit_check": pmj.get("unit_check"),
+                                       "what": "bytes per launch = (WRITE_SIZE + 2 x FETCH_SIZE) x 1024, rocprofv3 --pmc passes of tools/launch_timing.py --batch 64 (a committed run of the same launch on the same kernel sources, not this process)"}
+                        if "SQ_INSTS_VALU" in ent and isol:
+                            ms_dom = kernels[dom]["ms_isolated"]
+                            valu = {"SQ_INSTS_VALU_per_launch": ent["SQ_INSTS_VALU"], "wave_instructions_per_s": ent["SQ_INSTS_VALU"] / (ms_dom * 1e-3),
+                                    "chip_issue_rate_per_s": VALU_ISSUE_PER_S, "frac": ent["SQ_INSTS_VALU"] / (ms_dom * 1e-3) / VALU_ISSUE_PER_S,
+                                    "waves": ent.get("SQ_WAVES"), "simds": 1024, "waves_per_simd": (ent["SQ_WAVES"] / 1024 if ent.get("SQ_WAVES") else None)}
+                except Exception as e:      # a malformed evidence file must not take the bench line down
+                    traffic, traffic_src, valu = None, {"file": "profiles/r04_pmc_cfg3_bn254_b64.json", "why_null": repr(e)}, None
         out = {
             "metric": "FRI-verifier witness cells/sec", "value": value, "unit": "cells/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard_queries else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {desc}, {'PoseidonBN254' if hash_mode else 'Goldilocks-Poseidon'} Merkle, lookup_bits={args.lookup_bits}",
@@ -476,9 +579,17 @@ def main():
                        "layout": ("flat advice stream" if bps is None else f"FlexGate columns written directly: {len(bps) + 1} columns of 2^{args.k} rows per proof (break points of halo2-base assign_with_constraints, 9 unusable rows)"),
                        "merkle_path_passes": passes_timed if hash_mode == 1 else None,
                        "proofs": "valid FRI instances of random polynomials, generated on the GPU by the ingest rank (h2w_prove_fri_batch)" if args.proofs == "valid" and args.backend != "gloo" else "uniform random words of the proof's shape",
-                       "parallelism": (f"(proof, query) units of the same {B} proofs dealt round-robin to {world} ranks, prologue blocks to rank proof mod {world}; every rank launches only its own units "
+                       "parallelism": (f"(proof, query) units of the same {B} proofs dealt round-robin to {sh_world} ranks, prologue blocks to rank proof mod {sh_world}; every rank launches only its own units "
                                        f"({'packed per-rank advice buffers' if args.compact else 'blocks at their global offsets'}); one broadcast of the proofs, no data-path collective"
-                                       if shard_queries else f"proof-sharded x{world}, one broadcast of the proofs, no data-path collective")},
+                                       if shard_queries else f"proof-sharded x{world}, one broadcast of the proofs, no data-path collective"),
+                       "emulated_rank": ({"rank": sh_rank, "world": sh_world,
+                                          "what": f"ONE process on ONE GPU running exactly the launches rank {sh_rank} of {sh_world} runs (h2w_fri_witness_batch_shard_compact(rank, world) over the same {B} proofs; the broadcast skipped); "
+                                                  "value = that rank's own cells / s.  The path has no data-path collective, so this is the per-GPU rate of such a run; "
+                                                  f"node_projection = value x {sh_world} is arithmetic, not a measurement"} if emulate else None),
+                       "rank0_generation": ({"generated": n_generated, "resident": total_proofs, "budget_s": args.gen_budget_s,
+                                             "note": "rank 0 generates every proof of the step on its GPU before the one broadcast (cfg 3: ~16 proofs/s with PoseidonBN254 caps, 512 proofs at --gpus 8 = ~32 s); past the budget it repeats the proofs it has"}
+                                            if n_generated is not None else None)},
+            "node_projection": (value * sh_world if emulate else None),
             "proofs_per_s": total_cells / plan.num_cells / elapsed,
             "input_generation": ({"proofs": total_proofs, "seconds": round(gen_seconds, 3), "proofs_per_s": round(total_proofs / gen_seconds, 1), "where": "GPU of rank 0, outside the timed region"} if gen_seconds else None),
             "advice_GBps": value * 32 / 1e9,
@@ -487,6 +598,9 @@ def main():
             "kernel_ms_isolated_per_rank": per_rank,
             "expand_schedule_timed_region": schedule,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS if achieved else None),
+                         "limiter": ("instruction issue and the depth of a Merkle path, not bytes: one quad walks 18 dependent PoseidonBN254 permutations (~300 dependent Montgomery products each); the kernel is priced against "
+                                     "HBM because advice bytes are the metric's unit - valu_issue is its second roof" if names[dom].startswith("k_merkle_bn") else "HBM writes"),
+                         "valu_issue": valu, "valu_issue_frac": (valu["frac"] if valu else None),
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": kbytes.get(dom), "kernel": names[dom], "kernels": kernels,
                          "other_merkle_path_form": ({"merkle_path_passes": 2 if passes_timed == 1 else 1, "kernels": table(isol_other, None), "launch_ms_isolated": isol_other.get("launch")} if isol_other else None),
                          "whole_job_frac": value * 32 / 1e9 / HBM_PEAK_GBS / world,

@@ -178,6 +178,7 @@ SYMBOLS = {
     "h2w_plan_timing": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
     "h2w_plan_timing_ex": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
     "h2w_plan_shard_cells": (C.c_uint64, [_vp, C.c_uint64, C.c_int, C.c_int]),
+    "h2w_plan_shard_workspace_bytes": (C.c_uint64, [_vp, C.c_uint64, C.c_int, C.c_int]),
     "h2w_plan_shard_block": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "h2w_fri_witness_batch_shard_compact": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_int, C.c_int]),
     "h2w_plan_num_record_cells": (C.c_uint64, [_vp]),

@@ -323,6 +323,10 @@ class Plan:
     def shard_cells(self, n, rank, world):
         return int(self.L.h2w_plan_shard_cells(self.p, n, rank, world))
 
+    def shard_workspace_bytes(self, n, rank, world):
+        """Scratch bytes of a sharded call of this rank (the unit buffers hold the rank's own units only)."""
+        return int(self.L.h2w_plan_shard_workspace_bytes(self.p, n, rank, world))
+
     def shard_block(self, rank, world, proof, query):
         """(local cell, cells, global cell) of a block in rank's packed buffer; None when another rank owns it.  query < 0: the prologue block."""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -157,8 +157,31 @@ __global__ __launch_bounds__(256) void k_sbox_canon(BatchArgs A, uint32_t units_
     const unsigned i = (unsigned)(idx / per_q); const uint64_t v = idx % per_q;
     int p, q; if (!own_unit_at(A, i, p, q)) return;
     if (v >= A.st->q_nunit[q == 0 ? 0 : 1] * (uint64_t)(BN_PARTIAL_ROUNDS * 3)) return;
-    fr_t *const x = A.unit_sbox + ((uint64_t)p * A.st->total_unit + strand_q_unit(*A.st, q)) * (BN_PARTIAL_ROUNDS * 3) + v;
+    fr_t *const x = A.unit_sbox + (uint64_t)i * A.sh.unit_slot * (BN_PARTIAL_ROUNDS * 3) + v;
     g_store_fr(x, fr_mont_mul(g_load_fr(x), fr_from_u64(1), A.P.ninv));
+}
+// the same for the row-cooperative values pass (rowperm.h): it leaves every S-box value as twelve dwords of 29-bit limbs (times R, lazy, limbs a few
+// units above 2^29): carry pass, one Montgomery product by 1, one conditional subtraction -> the canonical value, into unit_sbox
+__global__ __launch_bounds__(256) void k_sbox_canon9(BatchArgs A, uint32_t units_per_query) {
+    const uint64_t per_q = (uint64_t)units_per_query * (BN_PARTIAL_ROUNDS * 3);
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned i = (unsigned)(idx / per_q); const uint64_t v = idx % per_q;
+    int p, q; if (!own_unit_at(A, i, p, q)) return;
+    if (v >= A.st->q_nunit[q == 0 ? 0 : 1] * (uint64_t)(BN_PARTIAL_ROUNDS * 3)) return;
+    const uint64_t at = (uint64_t)i * A.sh.unit_slot * (BN_PARTIAL_ROUNDS * 3) + v;
+    const uint4 *src = reinterpret_cast<const uint4 *>(A.unit_sbox9 + at * rf::SBX9_W);
+    const uint4 a = src[0], b = src[1], c4 = src[2];
+    const uint32_t t[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x};
+    fr9_t n; uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const uint32_t x = t[j] + c; n.t[j] = x & rf::M29; c = x >> 29; }
+    n.t[8] = t[8] + c;
+    fr9_t one9;
+#pragma unroll
+    for (int j = 0; j < 9; j++) one9.t[j] = j == 0 ? 1u : 0u;
+    fr_t s = fr9_pack(fr9_mont(n, one9, (uint32_t)A.P.ninv & rf::M29));
+    if (fr_geq_mod(s)) s = fr_sub_mod_raw(s);
+    g_store_fr(A.unit_sbox + at, s);
 }
 // one pass (H2W_OPT_CHAIN_PASSES 1): four lanes per (owned unit, kind) walk the path and emit every unit of it - the least arithmetic per
 // cell (352 wavefront-level products per permutation, none twice), serial in the path's depth; blockIdx.y = kind slot
@@ -173,7 +196,7 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR void
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     Sink sink;
-    quad_strand<QuadB>(A, sink, p, q, kind);
+    quad_strand<QuadB>(A, sink, idx, p, q, kind);
 }
 __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long *out4) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -203,7 +226,7 @@ struct h2w_plan {
     bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
     uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
     PlanEqualities eqs;
-    fr_t *d_bn_tab = nullptr; uint32_t *d_bn_tab9 = nullptr; FriTab *d_fri = nullptr; uint64_t nunit = 0;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
+    fr_t *d_bn_tab = nullptr; uint32_t *d_bn_tab9 = nullptr; FriTab *d_fri = nullptr; uint64_t nunit = 0; rf::RowConst *d_rowk = nullptr;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
     StrandTable *d_st = nullptr;                      // device copy of st
     bool small_mds = false;                           // Goldilocks-Poseidon MDS entries are tiny (coop.h glp_small_mds)
     uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
@@ -213,6 +236,7 @@ struct h2w_plan {
     hipEvent_t evr[EV_RING][N_EV]; int passes_of[EV_RING] = {0};
     hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
     int chain_passes = 0;            // H2W_OPT_CHAIN_PASSES (0: by the size of the launch)
+    int values_form = 0;             // H2W_OPT_VALUES_FORM (0: by the size of the launch)
     int serial_expand = 1;           // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's
     bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
     hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
@@ -305,6 +329,9 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
             std::vector<uint32_t> tab9((size_t)BK9_N * BK9_W); bn_table9_build(tab.data(), tab9.data());      // the values pass' limb-form copy
             H2W_HIP(hipMalloc((void **)&pl->d_bn_tab9, tab9.size() * sizeof(uint32_t)));
             H2W_HIP(hipMemcpy(pl->d_bn_tab9, tab9.data(), tab9.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            rf::RowConst rk; rf::rowconst_init(rk, pl->P);                                      // the row-cooperative values pass' constants (rowfr.h)
+            H2W_HIP(hipMalloc((void **)&pl->d_rowk, sizeof(rk)));
+            H2W_HIP(hipMemcpy(pl->d_rowk, &rk, sizeof(rk), hipMemcpyHostToDevice));
         }
         {   // the FRI gadgets' shape constants (valbackend.h FriTab): per-call host work in the reference, a table here
             FriTab ft; fri_tab_build(ft, pl->shape.degree_bits + pl->shape.rate_bits);
@@ -334,6 +361,7 @@ void h2w_plan_free(h2w_plan *p) {
     if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
     if (p->d_bn_tab9) (void)hipFree(p->d_bn_tab9);
+    if (p->d_rowk) (void)hipFree(p->d_rowk);
     if (p->d_fri) (void)hipFree(p->d_fri);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_st) (void)hipFree(p->d_st);
@@ -356,28 +384,39 @@ int h2w_plan_strand_layout(const h2w_plan *p, uint64_t out[4]) {
     out[0] = p->st.pro_ncell; out[1] = p->st.q_ncell[0]; out[2] = p->shape.num_queries > 1 ? p->st.q_ncell[1] : p->st.q_ncell[0]; out[3] = p->ncells;
     return 0;
 }
-uint64_t h2w_plan_num_chain_cells(const h2w_plan *p) {      // cells of the Merkle strands: what k_merkle_bn_quad writes per proof (hash_mode 1)
+uint64_t h2w_plan_num_chain_cells(const h2w_plan *p) {      // cells of the Merkle strands: what k_merkle_bn_fused writes per proof (hash_mode 1)
     if (!p) return 0;
     uint64_t n = 0;
     for (int k = 0; k < MK_KINDS; k++) n += p->st.mk_ncell[0][k] + (uint64_t)(p->shape.num_queries - 1) * p->st.mk_ncell[1][k];
     return n;
 }
-struct WsLayout { size_t recs, cbs, status, lflag, units, sbox, glp, ctr, total; };
-static WsLayout ws_layout(const h2w_plan *p, uint64_t n) {
+struct ShardSpec { int rank = 0, world = 1, compact = 0; };
+static uint64_t own_count(uint64_t total, int rank, int world) { return total > (uint64_t)rank ? (total - (uint64_t)rank + (uint64_t)world - 1) / (uint64_t)world : 0; }
+static uint32_t unit_slot_of(const h2w_plan *p) { return (uint32_t)(p->st.q_nunit[0] > p->st.q_nunit[1] ? p->st.q_nunit[0] : p->st.q_nunit[1]); }
+// Per-proof pieces first (their offsets do not depend on the sharding: h2w_plan_status finds the status words whatever call filled them), then the
+// PoseidonBN254 unit buffers, which hold the units of THIS RANK's (proof, query) units only.
+struct WsLayout { size_t recs, cbs, status, lflag, units, sbox, sbox9, glp, ctr, total; };
+static WsLayout ws_layout(const h2w_plan *p, uint64_t n, const ShardSpec &sh = ShardSpec()) {
     WsLayout w; size_t o = 0;
     w.recs = o; o += align_up((size_t)n * p->nrec * sizeof(rec_t), 256);
     w.cbs = o; o += align_up((size_t)n * sizeof(DevCB), 256);
     w.status = o; o += align_up((size_t)n * sizeof(uint32_t), 256);
     w.lflag = o; o += align_up((size_t)n * sizeof(uint32_t), 256);      // per proof: a word outside its field's range (k_prologue_load)
-    w.units = o; o += align_up((size_t)n * p->st.total_unit * 4 * sizeof(fr_t), 256);                  // PoseidonBN254 unit states (values phase -> emission)
-    w.sbox = o; o += align_up((size_t)n * p->st.total_unit * BN_PARTIAL_ROUNDS * 3 * sizeof(fr_t), 256);   // ... and the S-box values of their partial rounds
     w.glp = o; o += align_up((size_t)n * p->st.total_glp * GLP_LIST_WORDS * sizeof(uint64_t), 256);     // listed Goldilocks-Poseidon permutations
     w.ctr = o; o += align_up((size_t)n * sizeof(uint32_t), 256);                                       // expansion kernel's per-proof tile counters
+    const size_t own_units = (size_t)own_count(n * (uint64_t)p->shape.num_queries, sh.rank, sh.world) * unit_slot_of(p);
+    w.units = o; o += align_up(own_units * 4 * sizeof(fr_t), 256);                                     // PoseidonBN254 unit states (values phase -> emission)
+    w.sbox = o; o += align_up(own_units * BN_PARTIAL_ROUNDS * 3 * sizeof(fr_t), 256);                  // ... and the S-box values of their partial rounds
+    w.sbox9 = o; o += align_up(own_units * BN_PARTIAL_ROUNDS * 3 * rf::SBX9_W * sizeof(uint32_t), 256);  // ... in the limb form the row-cooperative values pass leaves them in
     w.total = o;
     return w;
 }
 uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) { return p ? ws_layout(p, n_proofs).total : 0; }
-struct ShardSpec { int rank = 0, world = 1, compact = 0; };
+uint64_t h2w_plan_shard_workspace_bytes(const h2w_plan *p, uint64_t n_proofs, int rank, int world) {
+    if (!p || world < 1 || rank < 0 || rank >= world) return 0;
+    ShardSpec sh; sh.rank = rank; sh.world = world;
+    return ws_layout(p, n_proofs, sh).total;
+}
 static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, void *emit_stream_, ColMap cm, uint64_t cell_stride, ShardSpec sh = ShardSpec());
 int h2w_fri_witness_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
     ColMap flat; flat.starts = nullptr; flat.ncols = 0; flat.k = 0;
@@ -434,7 +473,6 @@ int h2w_fri_witness_batch_shard(h2w_plan *p, const uint64_t *proofs_dev, uint64_
 }
 // The same blocks packed into a buffer of h2w_plan_shard_cells cells: the rank's owned blocks back to back in (proof, block) order.
 static uint64_t shard_q_slot(const h2w_plan *p) { return p->st.q_ncell[0] > p->st.q_ncell[1] ? p->st.q_ncell[0] : p->st.q_ncell[1]; }
-static uint64_t own_count(uint64_t total, int rank, int world) { return total > (uint64_t)rank ? (total - (uint64_t)rank + (uint64_t)world - 1) / (uint64_t)world : 0; }
 uint64_t h2w_plan_shard_cells(const h2w_plan *p, uint64_t n_proofs, int rank, int world) {
     if (!p || world < 1 || rank < 0 || rank >= world) return 0;
     return own_count(n_proofs, rank, world) * p->st.pro_ncell + own_count(n_proofs * (uint64_t)p->shape.num_queries, rank, world) * shard_q_slot(p);
@@ -473,19 +511,20 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
     if (n_proofs * (uint64_t)p->shape.num_queries * (p->st.mk_item0[MK_KINDS] ? p->st.mk_item0[MK_KINDS] : 1) > 0x3fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
+    if (n_proofs > 65535) { set_error("h2w_fri_witness_batch: more than 65535 proofs per call (the proof index is a grid dimension of the load and expansion kernels); split the batch"); return -1; }
     DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_, estream = (hipStream_t)emit_stream_;
-    const WsLayout wl = ws_layout(p, n_proofs);
+    const WsLayout wl = ws_layout(p, n_proofs, sh);
     char *ws = (char *)workspace_dev;
     BatchArgs A;
     A.shape = p->shape; A.consts = p->d_consts; A.proofs = proofs_dev; A.proof_words = p->pl.total;
     A.recs = (rec_t *)(ws + wl.recs); A.rec_stride = p->nrec; A.out = (fr_t *)advice_dev; A.cell_stride = cell_stride; A.cm = cm;
     A.cbs = (DevCB *)(ws + wl.cbs); A.status = (uint32_t *)(ws + wl.status);
-    A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
+    A.unit_state = (fr_t *)(ws + wl.units); A.unit_sbox = (fr_t *)(ws + wl.sbox); A.unit_sbox9 = (uint32_t *)(ws + wl.sbox9); A.rowk = p->d_rowk; A.glp_list = (uint64_t *)(ws + wl.glp); A.glp_small_mds = p->small_mds ? 1 : 0;
     A.bn_tab = p->d_bn_tab; A.bn_tab9 = p->d_bn_tab9; A.fri = p->d_fri;
     A.load_items = p->d_items; A.n_load_items = p->n_items; A.n_cap_items = p->n_cap_items; A.load_nrec = p->load_nrec; A.load_ncell = p->load_ncell; A.load_flag = (uint32_t *)(ws + wl.lflag);
     A.ncells = p->d_ncells; A.inv_pos = p->d_inv; A.inv_neg = p->d_inv + INV_TAB; A.st = p->d_st; A.P = p->P; A.nproofs = (int)n_proofs;
-    A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p);
+    A.sh.rank = sh.rank; A.sh.world = sh.world; A.sh.compact = sh.compact; A.sh.q_slot = shard_q_slot(p); A.sh.unit_slot = unit_slot_of(p);
     A.sh.n_own_units = (uint32_t)own_count(n_proofs * (uint64_t)p->shape.num_queries, sh.rank, sh.world);
     A.sh.n_own_proofs = (uint32_t)own_count(n_proofs, sh.rank, sh.world);
     hipStream_t cstream = stream;      // chain kernels' stream
@@ -536,10 +575,18 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             p->passes_of[p->n_batches % h2w_plan::EV_RING] = passes;
             if (nunits && passes == 1) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_fused<true>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_fused<false>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
             if (nunits && passes != 1) {
-                launch_merkle_bn_values(A, sgrid, cstream);
-                const uint32_t upq = (uint32_t)(p->st.q_nunit[0] > p->st.q_nunit[1] ? p->st.q_nunit[0] : p->st.q_nunit[1]);
+                // the values of the paths: one wavefront per path (rowperm.h: a path's 18 permutations in ~1.1 ms instead of 2.5) while the chip has a SIMD
+                // for (nearly) every path; four lanes per path (coop.h bn_values: a sixth of the instructions per path) beyond that
+                const bool rows = p->values_form ? p->values_form == 2 : (uint64_t)nunits * nkinds <= 2048;
+                const uint32_t upq = unit_slot_of(p);
                 const uint64_t nval = (uint64_t)nunits * upq * (BN_PARTIAL_ROUNDS * 3);
-                if (nval) hipLaunchKernelGGL(k_sbox_canon, dim3((unsigned)((nval + 255) / 256)), dim3(256), 0, cstream, A, upq);
+                if (rows) {
+                    launch_merkle_bn_values_row(A, nkinds, cstream);
+                    if (nval) hipLaunchKernelGGL(k_sbox_canon9, dim3((unsigned)((nval + 255) / 256)), dim3(256), 0, cstream, A, upq);
+                } else {
+                    launch_merkle_bn_values(A, sgrid, cstream);
+                    if (nval) hipLaunchKernelGGL(k_sbox_canon, dim3((unsigned)((nval + 255) / 256)), dim3(256), 0, cstream, A, upq);
+                }
             }
             H2W_HIP(hipEventRecord(ev[10], cstream));
             const unsigned long long items = passes == 1 ? 0ull : (unsigned long long)((nunits + 15u) & ~15u) * p->st.mk_item0[MK_KINDS];
@@ -920,6 +967,7 @@ int h2w_plan_configure(h2w_plan *p, int option, int value) {
     if (!p) { set_error("h2w_plan_configure: null plan"); return -1; }
     if (option == H2W_OPT_FORK_CHAINS) { p->fork_chains = value != 0; return 0; }
     if (option == H2W_OPT_SERIAL_EXPAND) { p->serial_expand = value != 0; return 0; }      // (negative: the default, on)
+    if (option == H2W_OPT_VALUES_FORM) { if (value < 0 || value > 2) { set_error("h2w_plan_configure: H2W_OPT_VALUES_FORM is 0 (by launch size), 1 (four lanes per path) or 2 (one wavefront per path)"); return -1; } p->values_form = value; return 0; }
     if (option == H2W_OPT_CHAIN_PASSES) { if (value < 0 || value > 2) { set_error("h2w_plan_configure: H2W_OPT_CHAIN_PASSES is 0 (by launch size), 1 or 2"); return -1; } p->chain_passes = value; return 0; }
     set_error("h2w_plan_configure: unknown option"); return -1;
 }

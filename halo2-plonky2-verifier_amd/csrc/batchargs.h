@@ -2,6 +2,7 @@
 #pragma once
 #include "valbackend.h"
 #include "coop.h"
+#include "rowfr.h"
 
 namespace h2w {
 
@@ -16,6 +17,7 @@ typedef ChallengeBlock<DevB> DevCB;   // (the wire types of every backend coinci
 // compact == 0: every block at its global offset in advice[n_proofs][num_cells].
 struct ShardMap {
     int rank, world, compact; uint32_t n_own_units, n_own_proofs; uint64_t q_slot;
+    uint32_t unit_slot;      // PoseidonBN254 permutation units of one (proof, query) unit: the rank's i-th unit keeps its unit states / S-box values at slot i (a rank's workspace holds its own units only)
 };
 
 struct BatchArgs {
@@ -30,8 +32,10 @@ struct BatchArgs {
     const fr_t *bn_tab;             // PoseidonBN254 tables of this plan: [2][BK_T] canonical / times R (coop.h bn_table_build)
     const FriTab *fri;              // the shape's FRI-gadget constants (valbackend.h FriTab)
     const uint32_t *bn_tab9;        // the times-R entries and the BK_X block in limb form (coop.h bn_table9_build): the values pass
-    fr_t *unit_state;               // [nproofs][st.total_unit][4]: output state of every PoseidonBN254 permutation unit (values phase -> emission)
-    fr_t *unit_sbox;                // [nproofs][st.total_unit][56][3]: canonical x^2, x^4, x^5 of its partial rounds' S-boxes
+    fr_t *unit_state;               // [own units][unit_slot][4]: output state of every PoseidonBN254 permutation unit of this rank's (proof, query) units (values phase -> emission)
+    fr_t *unit_sbox;                // [own units][unit_slot][56][3]: canonical x^2, x^4, x^5 of its partial rounds' S-boxes
+    uint32_t *unit_sbox9;           // the same values as the row-cooperative values pass leaves them: times R, lazy, 12 dwords of 29-bit limbs each (rowperm.h; k_sbox_canon9 -> unit_sbox)
+    const rf::RowConst *rowk;       // modulus, N' = -N^-1 mod 2^261 and R^2 in 29-bit limbs (rowfr.h), device memory of the plan
     uint64_t *glp_list;             // [nproofs][st.total_glp][GLP_LIST_WORDS]: the listed Goldilocks-Poseidon permutations (values phase -> record emission)
     int glp_small_mds;
     const LoadItem *load_items; uint32_t n_load_items, n_cap_items; uint64_t load_nrec, load_ncell; uint32_t *load_flag;      // load_items: n_load_items of the load phase, then n_cap_items cap hashes
@@ -84,11 +88,11 @@ template <bool COLS, bool VALPH, int HM> __device__ __forceinline__ void coop_si
 #define H2W_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(H2W_QUAD_EU, H2W_QUAD_EU)))
 
 // PoseidonBN254 Merkle chains (hash_mode 1).  A quad's strand: (owned unit, kind); its cursor, index bits and unit buffer.
-template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(const BatchArgs &A, Sink &sink, int p, int q, int kind) {
+template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(const BatchArgs &A, Sink &sink, unsigned own_idx, int p, int q, int kind) {
     const int sq = q == 0 ? 0 : 1;
     sink.recs = A.recs + (uint64_t)p * A.rec_stride; sink.out = block_out(A, p, q); sink.ncells = A.ncells; sink.l4 = threadIdx.x & 3; sink.cc.init(A.cm);
     sink.nrec = strand_q_rec(*A.st, q) + A.st->mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(*A.st, q) + A.st->mk_cell_rel[sq][kind];
-    const uint64_t unit0 = (uint64_t)p * A.st->total_unit + strand_q_unit(*A.st, q) + A.st->mk_unit_rel[sq][kind];
+    const uint64_t unit0 = (uint64_t)own_idx * A.sh.unit_slot + A.st->mk_unit_rel[sq][kind];
     sink.ustate = A.unit_state + unit0 * 4; sink.sbx = A.unit_sbox + unit0 * (BN_PARTIAL_ROUNDS * 3);
     ValCfg mc = make_cfg(A, p); mc.split_bn = true;
     QuadB be(sink, mc, !(q == 0 && kind == A.st->first_zero_kind));
@@ -104,6 +108,7 @@ template <class QuadB, class Sink> __device__ __forceinline__ void quad_strand(c
 void launch_glue_strands(const BatchArgs &A, hipStream_t stream);      // glue.hip
 void launch_merkle_bn_emit(const BatchArgs &A, dim3 grid, hipStream_t stream);      // glue.hip
 void launch_merkle_bn_values(const BatchArgs &A, dim3 grid, hipStream_t stream);    // glue.hip
+void launch_merkle_bn_values_row(const BatchArgs &A, unsigned nkinds, hipStream_t stream);    // glue.hip
 void launch_prologue_values(const BatchArgs &A, hipStream_t stream);   // glue.hip
 
 }  // namespace h2w

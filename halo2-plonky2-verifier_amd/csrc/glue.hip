@@ -15,8 +15,80 @@
 #include <hip/hip_runtime.h>
 #include "common.h"
 #include "batchargs.h"
+#define RF_TAB9 s_bn_tab9
+#include "rowperm.h"
 
 namespace h2w {
+
+// ---- the row-cooperative values pass (rowfr.h, rowperm.h): ONE wavefront per Merkle path, the four rows of the wavefront = the four elements of the
+// PoseidonBN254 state, one 29-bit limb per lane.  The wavefront walks its strand wave-uniformly (every lane runs the same gadget code on the same
+// values and writes nothing: the walk between two permutation units is a few selects); a permutation unit is rowperm.h bn_permute_rows.
+struct RowSink {
+    static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = true, kDevSponge = false; static constexpr int kHashMode = 1;
+    fr_t *ustate;                  // output states of this strand's permutation units, [unit][4]
+    uint32_t *sbx9;                // their partial rounds' S-box values in limb form, [unit][56][3][12]
+    const rf::RowConst *rowk; int unit_local = 0;
+    __device__ __forceinline__ void rec(int, uint64_t, uint64_t, uint64_t, uint64_t) {}
+    __device__ __forceinline__ void cell(const fr_t &) {}
+    __device__ __forceinline__ void gate() {}
+    __device__ __forceinline__ void lookup() {}
+    __device__ void note_cap_hash(uint64_t) {}
+    __device__ __forceinline__ void skip(uint64_t, uint64_t) {}
+    __device__ void merkle_begin(int, int, bool, uint64_t) {}
+    __device__ void merkle_end(int, int, bool) {}
+    __device__ void query_begin(int, uint64_t) {}
+    __device__ void query_end(int, uint64_t) {}
+    __device__ void bn_perm_begin(bool) {}
+    __device__ void bn_perm_end(bool) {}
+    __device__ void glp_note() {}
+    __device__ void note_load(uint64_t, int) {}
+    __device__ bool coop_load_proof(const ValCfg &) { return false; }
+    __device__ void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
+    __device__ __forceinline__ bool level_skip(fr_t &, bool &) { return false; }
+    __device__ __forceinline__ bool tail_skip() const { return true; }      // the cap lookup: cells only (no value anyone uses)
+    __device__ __noinline__ void permute_unit(fr_t *st) {
+        rf::RowConst K;
+        {   // wave-uniform: scalar loads
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(rowk); uint32_t *dst = reinterpret_cast<uint32_t *>(&K);
+#pragma unroll
+            for (unsigned i = 0; i < sizeof(rf::RowConst) / 4; i++) dst[i] = *(const __attribute__((address_space(4))) uint32_t *)(src + i);
+        }
+        const rf::LaneK L = rf::lane_consts();
+        rf::bn_permute_rows(st, K, L, sbx9 + (size_t)unit_local * (BN_PARTIAL_ROUNDS * 3 * rf::SBX9_W));
+        const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (lane == (unsigned)i) g_store_fr(ustate + (uint64_t)unit_local * 4 + i, st[i]);
+        unit_local++;
+    }
+    __device__ __forceinline__ bool bn_emit_inline(fr_t *st, const ValCfg &, bool &) { permute_unit(st); return true; }
+};
+__global__ __launch_bounds__(QUAD_BLOCK) __attribute__((flatten)) void k_merkle_bn_values_row(BatchArgs A) {
+    typedef ValBackend<RowSink> RowB;
+    stage_bn_consts9(A.bn_tab9, threadIdx.x, QUAD_BLOCK);    // (block-wide barrier inside: before any wavefront leaves)
+    const unsigned idx = blockIdx.x * QUAD_WAVES + (threadIdx.x >> 6);      // this wavefront's (proof, query) unit
+    int p, q;
+    if (!own_unit_at(A, idx, p, q)) return;
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    const int sq = q == 0 ? 0 : 1;
+    RowSink sink;
+    const uint64_t unit0 = (uint64_t)idx * A.sh.unit_slot + A.st->mk_unit_rel[sq][kind];
+    sink.ustate = A.unit_state + unit0 * 4; sink.sbx9 = A.unit_sbox9 + unit0 * (BN_PARTIAL_ROUNDS * 3 * rf::SBX9_W); sink.rowk = A.rowk;
+    ValCfg mc = make_cfg(A, p); mc.split_bn = true;
+    RowB be(sink, mc, !(q == 0 && kind == A.st->first_zero_kind));
+    const h2w_shape_t shp = A.shape;
+    Verifier<RowB> V(be, shp, A.consts);
+    const uint64_t x = A.cbs[p].fri_query_indices[q];
+    const int lde = V.d.lde_bits; int lo = 0;
+    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
+    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
+    V.merkle_strand(q, kind, PackedBits{x, lo}, lde - lo, cap_index);
+    if ((threadIdx.x & 63) == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+void launch_merkle_bn_values_row(const BatchArgs &A, unsigned nkinds, hipStream_t stream) {
+    const dim3 grid((A.sh.n_own_units + QUAD_WAVES - 1) / QUAD_WAVES, nkinds);
+    hipLaunchKernelGGL(k_merkle_bn_values_row, grid, dim3(QUAD_BLOCK), 0, stream, A);
+}
 
 // (the backends of this unit - DevSinkT<COLS, true> and CoopSinkT<COLS, true, -1> - are instantiated nowhere else: field.h, HNI)
 template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_strands(BatchArgs A) {
@@ -68,7 +140,7 @@ template <bool COLS> __global__ __launch_bounds__(QUAD_BLOCK) H2W_QUAD_ATTR __at
 #pragma unroll 1
     for (int k = 1; k < MK_KINDS; k++) if (item >= A.st->mk_item0[k]) kind = k;      // (kinds a shape does not have own no items)
     Sink sink; sink.set_window((int)(item - A.st->mk_item0[kind]), (int)A.st->mk_nunit[kind]);
-    quad_strand<QuadB>(A, sink, p, q, kind);
+    quad_strand<QuadB>(A, sink, ui, p, q, kind);
 }
 
 // values phase of the two-pass paths: four lanes per (owned unit, kind); blockIdx.y = kind slot.  In this (flattened) unit: the walk between two
@@ -84,7 +156,7 @@ __global__ __launch_bounds__(QUAD_BLOCK) __attribute__((flatten)) void k_merkle_
     const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
     const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
     Sink sink;
-    quad_strand<QuadB>(A, sink, p, q, kind);
+    quad_strand<QuadB>(A, sink, idx, p, q, kind);
 }
 void launch_merkle_bn_values(const BatchArgs &A, dim3 grid, hipStream_t stream) { hipLaunchKernelGGL(k_merkle_bn_values, grid, dim3(QUAD_BLOCK), 0, stream, A); }
 

@@ -251,6 +251,10 @@ int h2w_fri_witness_batch_shard(h2w_plan *, const uint64_t *proofs_dev, uint64_t
  * h2w_plan_shard_block: where a block lies - *local_cell in the packed buffer, *n_cells long, *global_cell its offset inside its proof's
  * flat stream; query < 0: the prologue block.  Returns 1 (and writes nothing) when the block belongs to another rank. */
 uint64_t h2w_plan_shard_cells(const h2w_plan *, uint64_t n_proofs, int rank, int world);
+/* Scratch bytes a sharded call (either form) of this rank needs for n_proofs: the per-proof pieces of h2w_plan_workspace_bytes plus the
+ * PoseidonBN254 unit buffers of the rank's own (proof, query) units only (1 / world of them).  A workspace of h2w_plan_workspace_bytes(n_proofs)
+ * bytes is always large enough. */
+uint64_t h2w_plan_shard_workspace_bytes(const h2w_plan *, uint64_t n_proofs, int rank, int world);
 int h2w_plan_shard_block(const h2w_plan *, int rank, int world, uint64_t proof, int query, uint64_t *local_cell, uint64_t *n_cells, uint64_t *global_cell);
 int h2w_fri_witness_batch_shard_compact(h2w_plan *, const uint64_t *proofs_dev, uint64_t n_proofs, void *shard_advice_dev, void *workspace_dev,
                                         void *stream, int rank, int world);
@@ -310,6 +314,11 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
  *    every permutation twice: right for small or sharded launches, which the depth of a path would otherwise bound.
  * 0 (default): 2 for launches of at most 512 (proof, query) units of this rank, else 1.  The cells are the same either way. */
 #define H2W_OPT_CHAIN_PASSES 3
+/* H2W_OPT_VALUES_FORM (PoseidonBN254 caps, two-pass paths): how the values pass walks a path.  1: four lanes per path (a Montgomery product on one
+ * lane); 2: one wavefront per path, a product spread over the 16 lanes of a row, one 29-bit limb per lane (a path in less than half the time, six
+ * times the instructions per path: right while there is a SIMD for nearly every path).  0 (default): 2 for launches of at most 2048 paths of this
+ * rank, else 1.  The cells are the same either way. */
+#define H2W_OPT_VALUES_FORM 4
 int h2w_plan_configure(h2w_plan *, int option, int value);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the streams it launches on:
  * ms[0] = prologue strands (values; with PoseidonBN254 caps also the records of their permutations), ms[1] = query glue strands (with

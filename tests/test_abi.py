@@ -127,8 +127,9 @@ def test_comm_entry_points_fail_loudly_without_a_device(h2w):
 
 
 def test_product_library_has_no_experiment_switches(h2w):
-    """The timing-experiment switches (H2W_DBG_* environment variables, tools/build_debug_variant.sh) exist only under -DH2W_DEBUG_HOOKS:
-    the library the tests, smoke() and bench.py load contains none of them (round 1 shipped wrong-output kernel variants behind getenv)."""
+    """No experiment switches exist in the sources any more (round 1 shipped wrong-output kernel variants behind getenv): kernel variants are
+    local patches / compile-time flags built as a separately named library by tools/experiments/variant.sh, and the library the tests, smoke()
+    and bench.py load reads no such environment variable."""
     blob = open(h2w.LIB_PATH, "rb").read()
     assert b"H2W_DBG" not in blob and b"H2W_EXPAND_VARIANT" not in blob and b"H2W_BN_UNITS" not in blob
     assert os.path.basename(h2w.LIB_PATH) == "libh2w.so" or os.environ.get("H2W_LIB")

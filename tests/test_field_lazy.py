@@ -23,6 +23,20 @@ def test_lazy_limb_products_agree_with_the_canonical_product(tmp_path):
     assert bits <= 261
 
 
+def test_lane_cooperative_products_and_permutation_on_simulated_lanes(tmp_path):
+    """csrc/rowfr.h + csrc/rowperm.h (the values pass with one 29-bit limb per lane, k_merkle_bn_values_row) with the 64 lanes of a wavefront
+    simulated on the host: products of lazy operands against the canonical product, limb and value bounds, no wrapped column sum, the carry rule of
+    the exact division, and the whole PoseidonBN254 permutation (output state and the 168 S-box values) against the reference walk."""
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = os.path.join(str(tmp_path), "rowfr_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "halo2-plonky2-verifier_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "rowfr_check.cpp"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert int(r.stdout.split("widest limb:")[1].split()[0]) < (1 << 29) + 8
+
+
 def test_fri_constants_table_equals_the_per_call_formulas(tmp_path):
     """chips.h FriTab (what h2w_plan_compile tabulates for the device strands) against the formulas the reference evaluates at every call."""
     if not shutil.which("g++"):

@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False, valid=False, cap_height=4, passes=0):
+def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, wlrc=1, split_streams=False, valid=False, cap_height=4, passes=0, values_form=0):
     import torch
     ko, kh = consts
     sh = h2w.fibonacci_shape(*shape_args[:2], rate_bits=shape_args[2], hash_mode=shape_args[3], lookup_bits=lookup_bits, witness_load_range_check=wlrc, cap_height=cap_height)
@@ -16,6 +16,8 @@ def run_batch(h2w, h2w_api, oracle, consts, shape_args, seeds, lookup_bits=21, w
     plan = h2w_api.Plan(sh, kh)
     if passes:
         plan.configure(3, passes)          # H2W_OPT_CHAIN_PASSES
+    if values_form:
+        plan.configure(4, values_form)     # H2W_OPT_VALUES_FORM
     n = len(seeds)
     proofs = [oracle.prove_fri(osh, ko, s) if valid else oracle.synth_proof(osh, s) for s in seeds]   # valid: oracle/prover.inc
     host = torch.empty(n * plan.proof_words, dtype=torch.int64)
@@ -55,13 +57,23 @@ def test_small_shapes_every_cell(h2w, h2w_api, oracle, consts, mode):
     run_batch(h2w, h2w_api, oracle, consts, (5, 1, 1, mode), [5, 6], wlrc=0)     # single query; SVG-era loader
 
 
-@pytest.mark.parametrize("passes", [1, 2])
-def test_merkle_paths_in_one_pass_and_in_two(h2w, h2w_api, oracle, consts, passes):
+@pytest.mark.parametrize("passes,form", [(1, 0), (2, 1), (2, 2)])
+def test_merkle_paths_in_one_pass_and_in_two(h2w, h2w_api, oracle, consts, passes, form):
     """H2W_OPT_CHAIN_PASSES: the PoseidonBN254 Merkle paths as one kernel that walks and emits (1) or as a values pass plus one quad per
-    permutation (2: every level of every path side by side).  Same cells; the default picks by the size of the launch."""
-    run_batch(h2w, h2w_api, oracle, consts, (8, 3, 2, 1), [61, 62, 63], passes=passes)          # one fold step, rate_bits 2
-    run_batch(h2w, h2w_api, oracle, consts, (10, 4, 1, 1), [0xF1B00001], passes=passes)         # BASELINE configs[0]
-    run_batch(h2w, h2w_api, oracle, consts, (4, 2, 1, 1), [64], passes=passes, cap_height=4)    # lde_bits 5: one-level paths, unit-less oracle strands
+    permutation (2: every level of every path side by side) - the values pass in both of its forms (H2W_OPT_VALUES_FORM: four lanes per path, a
+    Montgomery product on one lane | one wavefront per path, one 29-bit limb per lane: rowfr.h).  Same cells; the defaults pick by the size of the launch."""
+    run_batch(h2w, h2w_api, oracle, consts, (8, 3, 2, 1), [61, 62, 63], passes=passes, values_form=form)          # one fold step, rate_bits 2
+    run_batch(h2w, h2w_api, oracle, consts, (10, 4, 1, 1), [0xF1B00001], passes=passes, values_form=form)         # BASELINE configs[0]
+    run_batch(h2w, h2w_api, oracle, consts, (4, 2, 1, 1), [64], passes=passes, cap_height=4, values_form=form)    # lde_bits 5: one-level paths, unit-less oracle strands
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_values_pass_forms_on_the_published_tables_and_on_valid_proofs(h2w, h2w_api, oracle, consts, published, form):
+    """Both forms of the values pass under the published circomlib tables and under the seeded full-width ones, on a valid FRI instance (every
+    Merkle root then matches) and on random words; the last shape leaves the last block of four wavefronts partly filled."""
+    run_batch(h2w, h2w_api, oracle, published, (9, 2, 1, 1), [43], valid=True, cap_height=2, passes=2, values_form=form)
+    run_batch(h2w, h2w_api, oracle, published, (10, 4, 1, 1), [0xF1B00001, 0xF1B00002], passes=2, values_form=form)
+    run_batch(h2w, h2w_api, oracle, consts, (7, 5, 2, 1), [71, 72, 73, 74, 75, 76, 77], passes=2, values_form=form)      # 35 units: partly filled blocks of four wavefronts
 
 
 @pytest.mark.parametrize("lookup_bits", [13, 8, 17])
@@ -251,6 +263,67 @@ def test_packed_shard_layout(h2w, h2w_api, oracle, consts, mode):
         assert (got[:cells][~used] == -1).all()              # (slack of a query slot: untouched)
     assert (covered == 1).all()
     assert total < n * plan.num_cells + n * sh.num_queries + world          # no more than the stream plus one slack cell per query block
+    plan.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_packed_shard_layout_at_the_bench_launch_size(h2w, h2w_api, oracle, consts, mode):
+    """The schedule bench.py --shard-queries / --emulate-rank runs (VERDICT r03 task 1): a launch covers batch x world proofs, so that a rank of 8
+    has more than 512 (proof, query) units - the size at which the library walks the PoseidonBN254 Merkle paths in ONE pass (k_merkle_bn_fused) -,
+    its workspace is h2w_plan_shard_workspace_bytes (unit buffers of its own units only), its advice the packed buffer.  Every block of two ranks
+    equals the same block of the unsharded GPU stream of the same proofs, and that stream equals the oracle's for a sample of the proofs."""
+    import numpy as np
+    import torch
+    ko, kh = consts
+    nq, world = 5, 8
+    sh = h2w.fibonacci_shape(6, nq, rate_bits=2, hash_mode=mode); osh = oracle.fibonacci_shape(6, nq, rate_bits=2, hash_mode=mode)
+    plan = h2w_api.Plan(sh, kh)
+    n = 824 if mode == 1 else 48                    # 824 x 5 = 4120 units: 515 per rank
+    words = plan.proof_words
+    prng = np.random.default_rng(77)
+    host = torch.from_numpy(prng.integers(0, 1 << 60, n * words, dtype=np.int64))
+    d_proofs = host.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros((n, plan.num_cells, 4), dtype=torch.int64, device="cuda")
+    ws = torch.zeros(plan.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    plan.run(d_proofs.data_ptr(), n, full.data_ptr(), ws.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert plan.status(ws.data_ptr(), n, st) == [0] * n
+    if mode == 1:
+        assert int(plan.timing_ex(0)[7]) == 1
+    for i in (0, 1, n // 2, n - 1):                # the unsharded stream against the oracle
+        import ctypes
+        ctx = oracle.Ctx(21, track_scopes=False)
+        pr = (ctypes.c_uint64 * words).from_buffer_copy(host[i * words:(i + 1) * words].numpy().tobytes())
+        assert oracle.verify_stark(ctx, osh, ko, pr) == 0
+        assert full[i].cpu().numpy().tobytes() == ctx.advice_bytes(), i
+        ctx.close()
+    del ws
+    for rank in (0, 5):
+        cells = plan.shard_cells(n, rank, world)
+        wbytes = plan.shard_workspace_bytes(n, rank, world)
+        assert wbytes <= plan.workspace_bytes(n)
+        if mode == 1:
+            assert wbytes < plan.workspace_bytes(n)      # the unit buffers are the rank's own
+        buf = torch.full((cells + 8, 4), -1, dtype=torch.int64, device="cuda")
+        ws = torch.zeros(wbytes + 256, dtype=torch.uint8, device="cuda"); ws[wbytes:] = 0x5A      # guard bytes behind the workspace
+        plan.run_shard_compact(d_proofs.data_ptr(), n, buf.data_ptr(), ws.data_ptr(), rank, world, st)
+        torch.cuda.synchronize()
+        assert plan.status(ws.data_ptr(), n, st) == [0] * n
+        assert (ws[wbytes:] == 0x5A).all()
+        if mode == 1:
+            assert int(plan.timing_ex(0)[7]) == 1          # more than 512 units of this rank: the one-pass paths
+        assert (buf[cells:] == -1).all()
+        for p_ in range(n):
+            for q in range(-1, nq):
+                blk = plan.shard_block(rank, world, p_, q)
+                owner = (p_ % world) if q < 0 else (p_ * nq + q) % world
+                assert (blk is not None) == (owner == rank)
+                if blk is None:
+                    continue
+                lo, cnt, g = blk
+                assert torch.equal(buf[lo:lo + cnt], full[p_, g:g + cnt]), (rank, p_, q)
+        del buf, ws
     plan.close()
 
 

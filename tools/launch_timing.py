@@ -13,7 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg3"); ap.add_argument("--hash", default="bn254"); ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--world", type=int, default=1); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--compact", action="store_true"); ap.add_argument("--fork", action="store_true"); ap.add_argument("--passes", type=int, default=0)
+    ap.add_argument("--compact", action="store_true"); ap.add_argument("--fork", action="store_true"); ap.add_argument("--passes", type=int, default=0); ap.add_argument("--form", type=int, default=0)
     a = ap.parse_args()
     import torch
     import numpy as np
@@ -25,6 +25,8 @@ def main():
         plan.configure(1, 0)
     if a.passes:
         plan.configure(3, a.passes)
+    if a.form:
+        plan.configure(4, a.form)      # H2W_OPT_VALUES_FORM
     B = a.batch
     prng = np.random.default_rng(7)
     proofs = torch.from_numpy(prng.integers(0, 1 << 60, B * plan.proof_words, dtype=np.int64)).cuda()
@@ -42,7 +44,7 @@ def main():
         if i:
             out.append(plan.timing_ex(0))
     avg = [sum(t[k] for t in out) / len(out) for k in range(7)]
-    print(json.dumps({"config": a.config, "hash": a.hash, "batch": B, "world": a.world, "rank": a.rank, "compact": a.compact, "passes": a.passes, "advice_GB": cells * 32 / 1e9,
+    print(json.dumps({"config": a.config, "hash": a.hash, "batch": B, "world": a.world, "rank": a.rank, "compact": a.compact, "passes": a.passes, "values_form": a.form, "advice_GB": cells * 32 / 1e9,
                       "ms": {k: round(v, 3) for k, v in zip(KEYS, avg)}}))
 
 
