@@ -44,6 +44,11 @@ RF_FN V lo32(W w) { return (V)w; }
 RF_FN V hi32(W w) { return (V)(w >> 32); }
 RF_FN V sel(P p, V a, V b) { return p ? a : b; }
 RF_FN uint32_t rdlane(V v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+template <int J> RF_FN V quad_bcast(V v) { return (V)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false); }      // every lane <- lane J of its quad
+template <int N, int BANKS> RF_FN V shr_banks(V old, V v) { return (V)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 + N, 0xf, BANKS, false); }      // the quads in BANKS <- lane k - N; `old` elsewhere
+template <int N, int BANKS> RF_FN V shl_banks(V old, V v) { return (V)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x100 + N, 0xf, BANKS, false); }      // ... <- lane k + N
+// lanes `rows` of dst <- the wave-uniform value s (one v_mov under the lanes' mask; a select would cost a move of s into a register first)
+RF_FN void mov_rows(V &dst, P rows, uint32_t s) { if (rows) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "s"(s)); }
 // rows of v: [v0 v1 v2 v3] -> even = [v0 v0 v2 v2], odd = [v1 v1 v3 v3]   (v_permlane16_swap: odd rows of the first operand <-> even rows of the second)
 RF_FN void pair_bcast(V v, V &even, V &odd) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); even = r[0]; odd = r[1]; }
 // halves of v: [lo hi] -> low = [lo lo], high = [hi hi]                    (v_permlane32_swap: upper half of the first operand <-> lower half of the second)
@@ -85,6 +90,10 @@ inline V lo32(const W &w) { V r; RF_LANES(r.l[i] = (uint32_t)w.l[i]) return r; }
 inline V hi32(const W &w) { V r; RF_LANES(r.l[i] = (uint32_t)(w.l[i] >> 32)) return r; }
 inline V sel(const P &p, const V &a, const V &b) { V r; RF_LANES(r.l[i] = p.l[i] ? a.l[i] : b.l[i]) return r; }
 inline uint32_t rdlane(const V &v, int lane) { return v.l[lane]; }
+template <int J> inline V quad_bcast(const V &v) { V r; RF_LANES(r.l[i] = v.l[(i & ~3) + J]) return r; }
+template <int N, int BANKS> inline V shr_banks(const V &old, const V &v) { V r; RF_LANES(const int k = i & 15; r.l[i] = ((BANKS >> (k >> 2)) & 1) && k >= N ? v.l[i - N] : old.l[i]) return r; }
+template <int N, int BANKS> inline V shl_banks(const V &old, const V &v) { V r; RF_LANES(const int k = i & 15; r.l[i] = ((BANKS >> (k >> 2)) & 1) && k + N <= 15 ? v.l[i + N] : old.l[i]) return r; }
+inline void mov_rows(V &dst, const P &rows, uint32_t s) { RF_LANES(if (rows.l[i]) dst.l[i] = s) }
 inline void pair_bcast(const V &v, V &even, V &odd) { RF_LANES(const int row = i >> 4, k = i & 15; even.l[i] = v.l[(row & 2) * 16 + k]; odd.l[i] = v.l[((row & 2) + 1) * 16 + k]) }
 inline void half_bcast(const V &v, V &low, V &high) { RF_LANES(low.l[i] = v.l[i & 31]; high.l[i] = v.l[32 + (i & 31)]) }
 #endif
@@ -163,7 +172,22 @@ RF_FN void replicate(const V &v, int row, uint32_t out[9]) {
     for (int i = 0; i < 9; i++) out[i] = rdlane(v, 16 * row + i);
 }
 RF_FN void put_rows(A9 &A, const P &rows, const uint32_t limbs[9]) {
-    for (int i = 0; i < 9; i++) A.a[i] = sel(rows, V(limbs[i]), A.a[i]);
+    for (int i = 0; i < 9; i++) mov_rows(A.a[i], rows, limbs[i]);
+}
+// the same for every row at once, each row its own value: limb i of a row on the lanes i..15 of that row (the lanes below i multiply zeros: mont) and
+// limb 8 on lane 0 as well (where mont forms column 16).  DPP only: the lane's quad gets the limb from a quad_perm, the other quads from bank-masked row
+// shifts - 27 moves for the four rows of a wavefront (nine v_readlane + nine moves per ROW the other way).
+template <int I> RF_FN V bcast_limb(const V &v) {
+    const V x = quad_bcast<I & 3>(v);
+    if (I < 4) { const V y = shr_banks<4, 0x2>(x, x); return shr_banks<8, 0xc>(y, y); }
+    if (I < 8) { const V y = shr_banks<4, 0x4>(x, x); return shr_banks<8, 0x8>(y, x); }
+    const V y = shr_banks<4, 0x8>(x, x); return shl_banks<8, 0x1>(y, x);
+}
+RF_FN A9 replicate_rows(const V &v) {
+    A9 A;
+    A.a[0] = bcast_limb<0>(v); A.a[1] = bcast_limb<1>(v); A.a[2] = bcast_limb<2>(v); A.a[3] = bcast_limb<3>(v); A.a[4] = bcast_limb<4>(v);
+    A.a[5] = bcast_limb<5>(v); A.a[6] = bcast_limb<6>(v); A.a[7] = bcast_limb<7>(v); A.a[8] = bcast_limb<8>(v);
+    return A;
 }
 
 inline void rowconst_init(RowConst &K, const FrParams &P) {

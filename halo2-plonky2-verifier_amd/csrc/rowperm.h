@@ -70,17 +70,9 @@ RF_FN void bn_permute_rows(fr_t st[4], const RowConst &K, const LaneK &L, uint32
     }
     S = tighten(S + ld_dist(V((uint32_t)BK_C) + row, L));                                      // ark(0)
     auto sbox = [&]() {                                                                        // x^5 on every row: three products, each row its own replicated operand
-        auto rep_rows = [&](const V &v) {
-            A9 A; uint32_t t[9];
-            replicate(v, 0, t); for (int i = 0; i < 9; i++) A.a[i] = V(t[i]);
-            replicate(v, 1, t); put_rows(A, L.row1, t);
-            replicate(v, 2, t); put_rows(A, row == V(2u), t);
-            replicate(v, 3, t); put_rows(A, row == V(3u), t);
-            return A;
-        };
-        const V X2 = mont(rep_rows(S), S, K, L);
-        const V X4 = mont(rep_rows(X2), X2, K, L);
-        S = mont(rep_rows(X4), S, K, L);
+        const V X2 = mont(replicate_rows(S), S, K, L);
+        const V X4 = mont(replicate_rows(X2), X2, K, L);
+        S = mont(replicate_rows(X4), S, K, L);
     };
     // (an LDS read that is waited for where it stands costs a lone wavefront ~120 cycles: every table entry is read a product ahead of its use)
     struct MixK { A9 m0, m1, m2, m3; };
