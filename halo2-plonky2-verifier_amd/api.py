@@ -23,6 +23,10 @@ class Context:
             raise H2WError("h2w_ctx_new: " + last_error())
         self.lookup_bits = lookup_bits
 
+    def trace_begin(self):
+        """Record the op tape of this context's run (h2w_ctx_trace_begin; Plan.from_trace turns it into a replayable plan)."""
+        _ck(self.L.h2w_ctx_trace_begin(self.p), "h2w_ctx_trace_begin")
+
     def close(self):
         if getattr(self, "p", None):
             self.L.h2w_ctx_free(self.p)
@@ -217,10 +221,10 @@ class GoldilocksChip:
 class Plan:
     """Shape-compiled batched hot path (h2w_plan_* / h2w_fri_witness_batch)."""
 
-    def __init__(self, shape, consts, device_id=0):
+    def __init__(self, shape, consts, device_id=0, _handle=None):
         self.L = lib()
         self.shape, self.consts, self.device_id = shape, consts, device_id
-        self.p = self.L.h2w_plan_compile(C.byref(shape), C.byref(consts), device_id)
+        self.p = _handle if _handle is not None else self.L.h2w_plan_compile(C.byref(shape), C.byref(consts), device_id)
         if not self.p:
             raise H2WError("h2w_plan_compile: " + last_error())
         self.num_cells = int(self.L.h2w_plan_num_cells(self.p))
@@ -228,6 +232,18 @@ class Plan:
         self.num_records = int(self.L.h2w_plan_num_records(self.p))
         self.num_record_cells = int(self.L.h2w_plan_num_record_cells(self.p))
         self.num_chain_cells = int(self.L.h2w_plan_num_chain_cells(self.p))
+
+    @classmethod
+    def from_trace(cls, ctx, proof_words, parallel_scopes=("verify_query_round", "verify_proof_to_cap_with_cap_index"), device_id=0):
+        """h2w_plan_from_trace: the tape `ctx` recorded (Context.trace_begin, then ONE run through the level-1 / level-2 calls) as a plan that
+        h2w_fri_witness_batch replays on other proofs of the shape.  parallel_scopes: the #[count] scopes whose instances are independent
+        (fri/mod.rs:488-501, merkle/mod.rs:57-78); the library checks the claim on the tape."""
+        L = lib()
+        names = (C.c_char_p * len(parallel_scopes))(*[s.encode() for s in parallel_scopes])
+        h = L.h2w_plan_from_trace(ctx.p, proof_words, names, len(parallel_scopes), device_id)
+        if not h:
+            raise H2WError("h2w_plan_from_trace: " + last_error())
+        return cls(None, None, device_id, _handle=h)
 
     def close(self):
         if getattr(self, "p", None):

@@ -17,6 +17,9 @@ namespace h2w {
 struct AbiBackend {
     typedef h2w_assigned_t Gl; typedef h2w_assigned_t Bool; typedef h2w_assigned_t Fr; typedef h2w_assigned_t Big;
     static constexpr bool kCoopPoseidon = false, kSplitOnly = false, kBnUnits = false, kDevSponge = false; static constexpr int kHashMode = -1;
+    static constexpr bool kHintOps = true;      // the two hint sites of the reference (base.rs:382, extension.rs:327) are level-2 calls: no value leaves the library (trace.h)
+    Gl gl_div(const Gl &a, const Gl &b) { Gl o; memset(&o, 0, sizeof(o)); const int r = h2w_gl_div(ctx, &a, &b, &o); if (r != 0) { if (b.value.l[0] == 0 && (b.value.l[1] | b.value.l[2] | b.value.l[3]) == 0) fail(1); else ck(r); } return o; }
+    void ext_inv_witness(const Gl *a, Gl *out) { memset(out, 0, 2 * sizeof(Gl)); const int r = h2w_gl_ext_inv_witness(ctx, a, out); if (r != 0) { if ((a[0].value.l[0] | a[1].value.l[0]) == 0) fail(2); else ck(r); } }
     h2w_ctx *ctx; int mode; const uint64_t *proof; std::vector<h2w_assigned_t> wires; uint32_t status = 0; int rc = 0;
     AbiBackend(h2w_ctx *c, int hash_mode, const uint64_t *proof_words, size_t n_words) : ctx(c), mode(hash_mode), proof(proof_words), wires(n_words) {}
     void ck(int r) { if (r != 0 && rc == 0) rc = r; }
@@ -79,21 +82,23 @@ struct AbiBackend {
     // ---- proof wires
     Gl proof_gl(uint64_t w) { return wires[w]; }
     HashW<AbiBackend> proof_hash(uint64_t w) { HashW<AbiBackend> h; for (int i = 0; i < 4; i++) h.e[i] = wires[w + (mode == 0 ? i : 0)]; h.f = wires[w]; return h; }
-    void load_proof_gl(uint64_t w) { wires[w] = gl_witness(proof[w]); }
-    void load_proof_gl_nocheck(uint64_t w) { fr_t v = fr_from_u64(proof[w]); h2w_assigned_t o; ck(h2w_load_witness(ctx, &v, &o)); wires[w] = o; }
+    // proof words enter as tagged inputs (h2w_trace_input: a no-op unless the context is recording a trace)
+    void load_proof_gl(uint64_t w) { ck(h2w_trace_input(ctx, w, 1)); wires[w] = gl_witness(proof[w]); }
+    void load_proof_gl_nocheck(uint64_t w) { fr_t v = fr_from_u64(proof[w]); h2w_assigned_t o; ck(h2w_trace_input(ctx, w, 1)); ck(h2w_load_witness(ctx, &v, &o)); wires[w] = o; }
     void load_proof_hash(uint64_t w) {
-        if (mode == 0) for (int i = 0; i < 4; i++) wires[w + i] = gl_const(proof[w + i]);            // PoseidonChip::load_witness loads constants (hash.rs:86-96)
-        else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = proof[w + i]; wires[w] = fr_witness(v); }
+        if (mode == 0) for (int i = 0; i < 4; i++) { ck(h2w_trace_input(ctx, w + i, 1)); wires[w + i] = gl_const(proof[w + i]); }            // PoseidonChip::load_witness loads constants (hash.rs:86-96)
+        else { fr_t v; for (int i = 0; i < 4; i++) v.l[i] = proof[w + i]; ck(h2w_trace_input(ctx, w, 4)); wires[w] = fr_witness(v); }
     }
     bool coop_load_proof() { return false; }
     void note_cap_hash(uint64_t) {}
     bool merkle_split(int, int) { return false; }
     bool merkle_level_skip(HashW<AbiBackend> &) { return false; }
     bool merkle_tail_skip() { return false; }
-    void merkle_begin(int, int) {}
-    void merkle_end(int, int) {}
-    void query_begin(int) {}
-    void query_end(int) {}
+    // the scopes the reference's #[count] macro opens around these functions (macro/src/lib.rs:9-61; fri/mod.rs:337, merkle/mod.rs:56)
+    void merkle_begin(int, int) { ck(h2w_push_context(ctx, "verify_proof_to_cap_with_cap_index")); }
+    void merkle_end(int, int) { ck(h2w_pop_context(ctx)); }
+    void query_begin(int) { ck(h2w_push_context(ctx, "verify_query_round")); }
+    void query_end(int) { ck(h2w_pop_context(ctx)); }
     bool bn_perm_unit(Fr *, const h2w_poseidon_consts_t *) { return false; }
     void bn_perm_begin() {}
     void bn_perm_end() {}

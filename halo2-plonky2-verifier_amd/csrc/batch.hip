@@ -212,38 +212,14 @@ __global__ void k_digest(const ulonglong4 *cells, uint64_t n, unsigned long long
 
 using namespace h2w;
 
-struct h2w_plan;
-namespace h2w {
-PlanEqualities &plan_equalities(h2w_plan *p);
-}
-struct h2w_plan {
-    h2w_shape_t shape; int device;
-    TemplateTable tt; DeviceTables dt; StrandTable st; FrParams P;
-    Derived d; ProofLayout pl;
-    uint64_t nrec = 0, ncells = 0, rec_cells = 0;
-    LoadItem *d_items = nullptr; uint32_t n_items = 0, n_cap_items = 0; uint64_t load_nrec = 0, load_ncell = 0;      // d_items: the load phase's items, then the cap hashes'
-    h2w_poseidon_consts_t h_consts;                       // host copy (keygen-metadata replay)
-    bool meta_ready = false; std::vector<uint8_t> sel_bits, lk_bits; uint64_t n_gates = 0, n_lookups = 0; uint32_t *d_lookup_cells = nullptr; uint8_t *d_sel_bits = nullptr;
-    uint64_t *d_col_tab = nullptr; std::vector<uint64_t> h_col_tab; int col_k = -1;     // column-major emission: [starts | lens] of the last break-point set
-    PlanEqualities eqs;
-    fr_t *d_bn_tab = nullptr; uint32_t *d_bn_tab9 = nullptr; FriTab *d_fri = nullptr; uint64_t nunit = 0; rf::RowConst *d_rowk = nullptr;     // PoseidonBN254 tables of this plan (coop.h bn_table_build)
-    StrandTable *d_st = nullptr;                      // device copy of st
-    bool small_mds = false;                           // Goldilocks-Poseidon MDS entries are tiny (coop.h glp_small_mds)
-    uint64_t *d_meta = nullptr; h2w_poseidon_consts_t *d_consts = nullptr; uint16_t *d_ncells = nullptr; fr_t *d_inv = nullptr;
-    static constexpr int EV_RING = 64, N_EV = 13, N_SIDE = 16;
-    // per call: 0 start, 9 prologue values done, 11 / 12 permutation-record kernel start / end, 1 prologue block complete, 7 / 2 glue (+ Goldilocks Merkle
-    // strands) start / done, 8 / 3 expansion start / done, 4 / 10 / 5 chain kernels start / values done / end, 6 end of call
-    hipEvent_t evr[EV_RING][N_EV]; int passes_of[EV_RING] = {0};
-    hipStream_t side[N_SIDE]; hipStream_t side_of[N_SIDE]; int n_side = 0;   // PoseidonBN254 chain kernels run beside the glue + expansion kernels
-    int chain_passes = 0;            // H2W_OPT_CHAIN_PASSES (0: by the size of the launch)
-    int values_form = 0;             // H2W_OPT_VALUES_FORM (0: by the size of the launch)
-    int serial_expand = 1;           // H2W_OPT_SERIAL_EXPAND: the expansion kernel of a call waits for the previous call's
-    bool fork_chains = true;         // of their own batch (they share only the prologue): one side stream per caller stream seen (created on demand)
-    hipEvent_t *ev = evr[0]; uint64_t n_batches = 0; bool ev_ready = false, ev_recorded = false;
-    explicit h2w_plan(int L) : tt(L) {}
-};
+#include "plan.h"
 
 namespace h2w {
+// a traced plan (replay.hip)
+uint64_t traced_workspace_bytes(const h2w_plan *p, uint64_t n);
+uint64_t traced_status_offset(const h2w_plan *p, uint64_t n, bool flags);
+int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_);
+void traced_free(h2w_plan *p);
 PlanEqualities &plan_equalities(h2w_plan *p) { return p->eqs; }
 const h2w_shape_t &plan_shape(const h2w_plan *p) { return p->shape; }
 const h2w_poseidon_consts_t &plan_consts(const h2w_plan *p) { return p->h_consts; }
@@ -357,6 +333,7 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
 void h2w_plan_free(h2w_plan *p) {
     if (!p) return;
     DeviceGuard dg(p->device);
+    if (p->traced) traced_free(p);
     if (p->d_meta) (void)hipFree(p->d_meta);
     if (p->d_items) (void)hipFree(p->d_items);
     if (p->d_bn_tab) (void)hipFree(p->d_bn_tab);
@@ -411,7 +388,7 @@ static WsLayout ws_layout(const h2w_plan *p, uint64_t n, const ShardSpec &sh = S
     w.total = o;
     return w;
 }
-uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) { return p ? ws_layout(p, n_proofs).total : 0; }
+uint64_t h2w_plan_workspace_bytes(const h2w_plan *p, uint64_t n_proofs) { return !p ? 0 : p->traced ? traced_workspace_bytes(p, n_proofs) : ws_layout(p, n_proofs).total; }
 uint64_t h2w_plan_shard_workspace_bytes(const h2w_plan *p, uint64_t n_proofs, int rank, int world) {
     if (!p || world < 1 || rank < 0 || rank >= world) return 0;
     ShardSpec sh; sh.rank = rank; sh.world = world;
@@ -510,6 +487,10 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
+    if (p->traced) {      // a recorded run (replay.hip): the flat stream, unsharded
+        if (cm.starts || sh.world > 1 || emit_stream_ != stream_) { set_error("h2w_fri_witness_batch: a traced plan writes the flat advice stream on one stream, unsharded"); return -1; }
+        return traced_run(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_);
+    }
     if (n_proofs * (uint64_t)p->shape.num_queries * (p->st.mk_item0[MK_KINDS] ? p->st.mk_item0[MK_KINDS] : 1) > 0x3fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
     if (n_proofs > 65535) { set_error("h2w_fri_witness_batch: more than 65535 proofs per call (the proof index is a grid dimension of the load and expansion kernels); split the batch"); return -1; }
     DeviceGuard dg(p->device);
@@ -650,6 +631,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
 // expansion kernel alone, for measuring its streaming rate (bench.py roofline).  Cells written by the value kernels are not touched.
 int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
     if (!p || p->device < 0) { set_error("h2w_fri_expand_records: no HIP device"); return -1; }
+    if (p->traced) { set_error("h2w_fri_expand_records: not for traced plans"); return -1; }
     if (!advice_dev || !workspace_dev) { set_error("h2w_fri_expand_records: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
     DeviceGuard dg(p->device);
@@ -672,6 +654,7 @@ int h2w_fri_expand_records(h2w_plan *p, uint64_t n_proofs, void *advice_dev, voi
 // ---- keygen-side metadata of the cell stream: static per shape, computed by a second host replay
 int h2w_plan_metadata(h2w_plan *pl) {
     if (!pl) { set_error("h2w_plan_metadata: null plan"); return -1; }
+    if (pl->traced) { set_error("h2w_plan_metadata: a traced plan has no shape to replay on the host (the tracing context recorded the keygen lists: h2w_ctx_* with witness_gen_only = 0)"); return -1; }
     if (pl->meta_ready) return 0;
     if (pl->shape.lookup_bits >= 48) { set_error("h2w_plan_metadata: lookup_bits >= 48 makes a single-limb range check look up its SOURCE cell; not tracked"); return -1; }
     std::vector<fr_t> inv(2 * INV_TAB, fr_zero());
@@ -889,7 +872,8 @@ int h2w_check_equalities(const void *advice_dev, uint64_t n_cells, uint64_t proo
 }
 int h2w_plan_status(h2w_plan *p, const void *workspace_dev, uint64_t n_proofs, uint32_t *host_status, void *stream_) {
     if (!p || !workspace_dev || !host_status) { set_error("h2w_plan_status: null argument"); return -1; }
-    const WsLayout wl = ws_layout(p, n_proofs);
+    WsLayout wl = ws_layout(p, n_proofs);
+    if (p->traced) { wl.status = traced_status_offset(p, n_proofs, false); wl.lflag = traced_status_offset(p, n_proofs, true); }
     DeviceGuard dg(p->device);
     hipStream_t stream = (hipStream_t)stream_;
     std::vector<uint32_t> flag((size_t)n_proofs);

@@ -110,6 +110,7 @@ template <class B> struct GoldilocksChip {
     HF Gl const_mul(uint64_t k, Gl x) { return be.glop(PRE_A, be.gl_lit(k), x, be.gl_lit(0)); }     // c = load_constant(k); mul(c, x)
     HF Gl const_mul_add(uint64_t k, Gl x, Gl acc) { return be.glop(PRE_A, be.gl_lit(k), x, acc); }  // c = load_constant(k); mul_add(c, x, acc)
     HNI Gl div(Gl a, Gl b) {                                                                         // :371-393
+        if constexpr (B::kHintOps) return be.gl_div(a, b);      // the hint (:382) and its cells are the boundary's: one level-2 call (h2w_gl_div), replayable
         uint64_t bv = be.gl_val(b), av = be.gl_val(a);
         if (bv == 0) { be.fail(1); bv = 1; }                 // reference: assert!(b != 0) (:379)
         Gl res = load_witness(gl_mul(av, gl_inv(bv)));
@@ -172,9 +173,13 @@ template <class B> struct QuadExtChip {
     HF Ex mul_add(const Ex &a, const Ex &b, const Ex &c) { Ex ab = mul(a, b); return add(ab, c); }   // :284-294
     HF Ex mul_sub(const Ex &a, const Ex &b, const Ex &c) { Ex ab = mul(a, b); return sub(ab, c); }   // :308-318
     HNI Ex inv(const Ex &a) {                                                          // :320-340
-        gle_t av = value(a);
-        if (av.c[0] == 0 && av.c[1] == 0) { be.fail(2); av.c[0] = 1; }
-        Ex i = load_witness(gle_inv(av));
+        Ex i;
+        if constexpr (B::kHintOps) be.ext_inv_witness(a.e, i.e);      // the hint (:327) is the boundary's (h2w_gl_ext_inv_witness)
+        else {
+            gle_t av = value(a);
+            if (av.c[0] == 0 && av.c[1] == 0) { be.fail(2); av.c[0] = 1; }
+            i = load_witness(gle_inv(av));
+        }
         Ex pr = mul(a, i), one = load_one();                  // assert_equal(product, one): no cells
         be.assert_equal(pr.e[0], one.e[0]); be.assert_equal(pr.e[1], one.e[1]);
         return i;

@@ -15,6 +15,7 @@
 #include "records.h"
 #include "common.h"
 #include "keygen.h"
+#include "trace.h"
 #include "poseidon_tables.h"
 
 namespace h2w {
@@ -43,12 +44,25 @@ struct h2w_ctx {
     void *d_out = nullptr, *d_meta = nullptr, *d_recs = nullptr, *d_pool = nullptr;
     DeviceTables dt;
     bool dt_ready = false; size_t dt_nslots = 0, dt_nconsts = 0, dt_ntmpl = 0;
+    Trace *trace = nullptr;      // trace mode (h2w_ctx_trace_begin): the op tape of this run (trace.h)
     explicit h2w_ctx(int L_) : tt(L_) {}
+    ~h2w_ctx() { delete trace; }
 };
 
 namespace {
 
 typedef h2w_assigned_t Av;
+// ---- trace mode: one tape entry per call (trace.h).  TrRec is opened before the call's cells are appended and closed after.
+struct TrRec {
+    h2w_ctx *c; Trace *t; TraceOp op;
+    TrRec(h2w_ctx *c_, uint16_t code, uint16_t sub = 0, uint64_t imm = 0);
+    void in(const Av *a) { if (!t) return; if (!a->has_cell || a->ctx_id != ctx_id()) t->fail("trace: an operand is not a cell of this context (a value that bypassed the library cannot be replayed)"); t->ins.push_back(TraceIn{a->offset, 0}); op.n_in++; }
+    void lit(uint64_t v) { if (!t) return; t->ins.push_back(TraceIn{v, 1}); op.n_in++; }
+    void out(const Av *a) { if (!t) return; t->outs.push_back(a->offset); op.n_out++; }
+    void tag_required(const char *fn);
+    void done();
+    uint32_t ctx_id() const;
+};
 inline bool fits64(const fr_t &v) { return (v.l[1] | v.l[2] | v.l[3]) == 0; }
 inline Av mk(h2w_ctx *c, const fr_t &v, uint64_t off) { Av a; a.value = v; a.offset = off; a.ctx_id = c->id; a.has_cell = 1; return a; }
 
@@ -167,6 +181,15 @@ bool check(h2w_ctx *c, const char *fn) {
 int fail(h2w_ctx *c, const std::string &msg) { if (c) c->err = 1; set_error(msg); return -1; }
 inline int kg_done(h2w_ctx *c, const char *fn) { if (c->keygen && c->mr.row != c->ncells) return fail(c, std::string(fn) + ": internal: keygen bookkeeping out of step with the cell stream"); return 0; }
 
+TrRec::TrRec(h2w_ctx *c_, uint16_t code, uint16_t sub, uint64_t imm) : c(c_), t(c_ ? c_->trace : nullptr) {
+    if (!t) return;
+    op.code = code; op.sub = sub; op.imm = imm; op.n_in = op.n_out = 0; op.first_in = (uint32_t)t->ins.size(); op.first_out = (uint32_t)t->outs.size();
+    op.cell0 = c->ncells; op.ncells = 0; op.tag = t->pending; t->pending = TraceTag();
+}
+uint32_t TrRec::ctx_id() const { return c->id; }
+void TrRec::tag_required(const char *fn) { if (t && op.tag.kind == 0) t->fail(std::string(fn) + ": a witness whose value the library cannot recompute on another proof (tag it with h2w_trace_input, or use the level-2 hint ops)"); }
+void TrRec::done() { if (!t) return; op.ncells = (uint32_t)(c->ncells - op.cell0); t->ops.push_back(op); }
+
 }  // namespace
 
 extern "C" {
@@ -197,54 +220,82 @@ void h2w_ctx_free(h2w_ctx *c) {
 uint64_t h2w_num_cells(const h2w_ctx *c) { return c ? c->ncells : 0; }
 int h2w_ctx_error(const h2w_ctx *c) { return c ? c->err : 1; }
 
-int h2w_load_constant(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_constant")) return -1; if (c->keygen) c->mr.load_constant(*v); cell(c, *v); *out = mk(c, *v, c->ncells - 1); return kg_done(c, "h2w_load_constant"); }
-int h2w_load_witness(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) { if (!check(c, "h2w_load_witness")) return -1; if (c->keygen) c->mr.load_witness(); cell(c, *v); *out = mk(c, *v, c->ncells - 1); return kg_done(c, "h2w_load_witness"); }
+int h2w_load_constant(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) {
+    if (!check(c, "h2w_load_constant")) return -1;
+    TrRec tr(c, TR_LOAD_CONSTANT); if (tr.t) { tr.op.imm = tr.t->consts.size(); tr.t->consts.push_back(*v); }
+    if (c->keygen) c->mr.load_constant(*v);
+    cell(c, *v); *out = mk(c, *v, c->ncells - 1); tr.out(out); tr.done(); return kg_done(c, "h2w_load_constant");
+}
+int h2w_load_witness(h2w_ctx *c, const h2w_fr_t *v, h2w_assigned_t *out) {
+    if (!check(c, "h2w_load_witness")) return -1;
+    TrRec tr(c, TR_LOAD_WITNESS); tr.tag_required("h2w_load_witness");
+    if (c->keygen) c->mr.load_witness();
+    cell(c, *v); *out = mk(c, *v, c->ncells - 1); tr.out(out); tr.done(); return kg_done(c, "h2w_load_witness");
+}
 int h2w_load_zero(h2w_ctx *c, h2w_assigned_t *out) {
     if (!check(c, "h2w_load_zero")) return -1;
-    if (!c->zero_set) { if (c->keygen) c->mr.load_constant(fr_zero()); cell(c, fr_zero()); c->zero_set = true; c->zero_off = c->ncells - 1; }
+    if (!c->zero_set) {
+        TrRec tr(c, TR_LOAD_CONSTANT); if (tr.t) { tr.op.imm = tr.t->consts.size(); tr.t->consts.push_back(fr_zero()); }
+        if (c->keygen) c->mr.load_constant(fr_zero());
+        cell(c, fr_zero()); c->zero_set = true; c->zero_off = c->ncells - 1;
+        const h2w_assigned_t z = mk(c, fr_zero(), c->zero_off); tr.out(&z); tr.done();
+    }
     *out = mk(c, fr_zero(), c->zero_off); return 0;
 }
 int h2w_load_constants(h2w_ctx *c, const h2w_fr_t *v, size_t n, h2w_assigned_t *out) {
     if (!check(c, "h2w_load_constants")) return -1;
-    for (size_t i = 0; i < n; i++) { if (c->keygen) c->mr.load_constant(v[i]); cell(c, v[i]); out[i] = mk(c, v[i], c->ncells - 1); }
+    for (size_t i = 0; i < n; i++) {
+        TrRec tr(c, TR_LOAD_CONSTANT); if (tr.t) { tr.op.imm = tr.t->consts.size(); tr.t->consts.push_back(v[i]); }
+        if (c->keygen) c->mr.load_constant(v[i]);
+        cell(c, v[i]); out[i] = mk(c, v[i], c->ncells - 1); tr.out(out + i); tr.done();
+    }
     return kg_done(c, "h2w_load_constants");
 }
 int h2w_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     if (!check(c, "h2w_add")) return -1;
+    TrRec tr(c, TR_ADD); tr.in(a); tr.in(b);
     if (c->keygen) c->mr.add(MR::EX(off(a)), MR::EX(off(b)));
-    *out = t_gate(c, a->value, b->value, fr_from_u64(1)); return kg_done(c, "h2w_add");      // [a, b, 1, a+b]
+    *out = t_gate(c, a->value, b->value, fr_from_u64(1)); tr.out(out); tr.done(); return kg_done(c, "h2w_add");      // [a, b, 1, a+b]
 }
 int h2w_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     if (!check(c, "h2w_mul")) return -1;
+    TrRec tr(c, TR_MUL); tr.in(a); tr.in(b);
     if (c->keygen) c->mr.mul(MR::EX(off(a)), MR::EX(off(b)));
-    *out = t_gate(c, fr_zero(), a->value, b->value); return kg_done(c, "h2w_mul");          // [0, a, b, a*b]
+    *out = t_gate(c, fr_zero(), a->value, b->value); tr.out(out); tr.done(); return kg_done(c, "h2w_mul");          // [0, a, b, a*b]
 }
 int h2w_mul_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
     if (!check(c, "h2w_mul_add")) return -1;
+    TrRec tr(c, TR_MUL_ADD); tr.in(a); tr.in(b); tr.in(cc);
     if (c->keygen) c->mr.mul_add(MR::EX(off(a)), MR::EX(off(b)), MR::EX(off(cc)));
-    *out = t_gate(c, cc->value, a->value, b->value); return kg_done(c, "h2w_mul_add");          // [c, a, b, a*b+c]
+    *out = t_gate(c, cc->value, a->value, b->value); tr.out(out); tr.done(); return kg_done(c, "h2w_mul_add");          // [c, a, b, a*b+c]
 }
 int h2w_select(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *sel, h2w_assigned_t *out) {
     if (!check(c, "h2w_select")) return -1;
+    TrRec tr(c, TR_SELECT); tr.in(a); tr.in(b); tr.in(sel);
     if (c->keygen) c->mr.select(MR::EX(off(a)), MR::EX(off(b)), MR::EX(off(sel)));
-    *out = t_select(c, a->value, b->value, sel->value); return kg_done(c, "h2w_select");
+    *out = t_select(c, a->value, b->value, sel->value); tr.out(out); tr.done(); return kg_done(c, "h2w_select");
 }
 int h2w_idx_to_indicator(h2w_ctx *c, const h2w_assigned_t *idx, size_t len, h2w_assigned_t *out) {
     if (!check(c, "h2w_idx_to_indicator")) return -1;
+    TrRec tr(c, TR_IDX_TO_INDICATOR, 0, len); tr.in(idx);
     if (c->keygen) { std::vector<int64_t> o(len); c->mr.idx_to_indicator(off(idx), len, o.data()); }
-    t_idx_to_indicator(c, idx->value, len, out); return kg_done(c, "h2w_idx_to_indicator");
+    t_idx_to_indicator(c, idx->value, len, out); for (size_t i = 0; i < len; i++) tr.out(out + i); tr.done(); return kg_done(c, "h2w_idx_to_indicator");
 }
 int h2w_select_from_idx(h2w_ctx *c, const h2w_assigned_t *arr, size_t n, const h2w_assigned_t *idx, h2w_assigned_t *out) {
     if (!check(c, "h2w_select_from_idx")) return -1;
     std::vector<Av> ind(n);
     if (c->keygen) { std::vector<int64_t> o(n), ao(n); c->mr.idx_to_indicator(off(idx), n, o.data()); for (size_t i = 0; i < n; i++) ao[i] = off(arr + i); c->mr.select_by_indicator(ao.data(), 1, o.data(), n); }
-    t_idx_to_indicator(c, idx->value, n, ind.data());
-    *out = t_select_by_indicator(c, arr, 1, ind.data(), n); return kg_done(c, "h2w_select_from_idx");
+    { TrRec tr(c, TR_IDX_TO_INDICATOR, 0, n); tr.in(idx); t_idx_to_indicator(c, idx->value, n, ind.data()); for (size_t i = 0; i < n; i++) tr.out(&ind[i]); tr.done(); }
+    TrRec tr(c, TR_SELECT_BY_INDICATOR, 0, n); for (size_t i = 0; i < n; i++) tr.in(arr + i); for (size_t i = 0; i < n; i++) tr.in(&ind[i]);
+    *out = t_select_by_indicator(c, arr, 1, ind.data(), n); tr.out(out); tr.done(); return kg_done(c, "h2w_select_from_idx");
 }
 int h2w_select_array_by_indicator(h2w_ctx *c, const h2w_assigned_t *arr2d, size_t len, size_t w, const h2w_assigned_t *ind, h2w_assigned_t *out) {
     if (!check(c, "h2w_select_array_by_indicator")) return -1;
     if (c->keygen) { std::vector<int64_t> ao(len * w), io(len); for (size_t i = 0; i < len * w; i++) ao[i] = off(arr2d + i); for (size_t i = 0; i < len; i++) io[i] = off(ind + i); for (size_t j = 0; j < w; j++) c->mr.select_by_indicator(ao.data() + j, w, io.data(), len); }
-    for (size_t j = 0; j < w; j++) out[j] = t_select_by_indicator(c, arr2d + j, w, ind, len);
+    for (size_t j = 0; j < w; j++) {
+        TrRec tr(c, TR_SELECT_BY_INDICATOR, 0, len); for (size_t i = 0; i < len; i++) tr.in(arr2d + i * w + j); for (size_t i = 0; i < len; i++) tr.in(ind + i);
+        out[j] = t_select_by_indicator(c, arr2d + j, w, ind, len); tr.out(out + j); tr.done();
+    }
     return kg_done(c, "h2w_select_array_by_indicator");
 }
 int h2w_num_to_bits(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits, h2w_assigned_t *out) {
@@ -252,48 +303,55 @@ int h2w_num_to_bits(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits, h2w_
     if (range_bits == 0 || range_bits > 253) return fail(c, "h2w_num_to_bits: range_bits out of range");
     std::vector<fr_t> bits(range_bits), bases(range_bits);
     for (size_t i = 0; i < range_bits; i++) { bits[i] = fr_from_u64(fr_bits(a->value, (int)i, 1)); bases[i] = fr_pow2((int)i); }
+    TrRec tr(c, TR_NUM_TO_BITS, 0, range_bits); tr.in(a);
     if (c->keygen) { std::vector<int64_t> o(range_bits); c->mr.num_to_bits(off(a), range_bits, o.data()); }
     uint64_t row = c->ncells;
     t_inner_product(c, bits.data(), bases.data(), range_bits);
     out[0] = mk(c, bits[0], row);
     for (size_t i = 1; i < range_bits; i++) out[i] = mk(c, bits[i], row + 1 + 3 * (i - 1));
     for (size_t i = 0; i < range_bits; i++) t_assert_bit(c, bits[i]);
-    return kg_done(c, "h2w_num_to_bits");
+    for (size_t i = 0; i < range_bits; i++) tr.out(out + i);
+    tr.done(); return kg_done(c, "h2w_num_to_bits");
 }
 int h2w_bits_to_num(h2w_ctx *c, const h2w_assigned_t *bits, size_t n, h2w_assigned_t *out) {
     if (!check(c, "h2w_bits_to_num")) return -1;
     std::vector<fr_t> a(n), b(n);
     for (size_t i = 0; i < n; i++) { a[i] = bits[i].value; b[i] = fr_pow2((int)i); }
+    TrRec tr(c, TR_BITS_TO_NUM, 0, n); for (size_t i = 0; i < n; i++) tr.in(bits + i);
     if (c->keygen) { std::vector<int64_t> o(n); for (size_t i = 0; i < n; i++) o[i] = off(bits + i); c->mr.bits_or_limbs_to_num(o.data(), n, 1); }
-    *out = t_inner_product(c, a.data(), b.data(), n); return kg_done(c, "h2w_bits_to_num");
+    *out = t_inner_product(c, a.data(), b.data(), n); tr.out(out); tr.done(); return kg_done(c, "h2w_bits_to_num");
 }
 int h2w_decompose_le(h2w_ctx *c, const h2w_assigned_t *num, size_t limb_bits, size_t num_limbs, h2w_assigned_t *out) {
     if (!check(c, "h2w_decompose_le")) return -1;
     if (limb_bits == 0 || limb_bits > 64) return fail(c, "h2w_decompose_le: limb_bits out of range");
     std::vector<fr_t> limbs(num_limbs), bases(num_limbs);
     for (size_t i = 0; i < num_limbs; i++) { limbs[i] = fr_from_u64(fr_bits(num->value, (int)(i * limb_bits), (int)limb_bits)); bases[i] = fr_pow2((int)(i * limb_bits)); }
+    TrRec tr(c, TR_DECOMPOSE_LE, 0, ((uint64_t)limb_bits << 32) | (uint64_t)num_limbs); tr.in(num);
     if (c->keygen) { std::vector<int64_t> o(num_limbs); c->mr.decompose_le(off(num), limb_bits, num_limbs, o.data()); }
     uint64_t row = c->ncells;
     t_inner_product(c, limbs.data(), bases.data(), num_limbs);
     out[0] = mk(c, limbs[0], row);
     for (size_t i = 0; i + 1 < num_limbs; i++) out[i + 1] = mk(c, limbs[i + 1], row + 1 + 3 * i);
     for (size_t i = 0; i < num_limbs; i++) t_range_check(c, out[i], limb_bits);
-    return kg_done(c, "h2w_decompose_le");
+    for (size_t i = 0; i < num_limbs; i++) tr.out(out + i);
+    tr.done(); return kg_done(c, "h2w_decompose_le");
 }
 int h2w_limbs_to_num(h2w_ctx *c, const h2w_assigned_t *limbs, size_t n, size_t limb_bits, h2w_assigned_t *out) {
     if (!check(c, "h2w_limbs_to_num")) return -1;
     std::vector<fr_t> a(n), b(n);
     for (size_t i = 0; i < n; i++) { a[i] = limbs[i].value; b[i] = fr_pow2((int)(i * limb_bits)); }
+    TrRec tr(c, TR_LIMBS_TO_NUM, 0, limb_bits); for (size_t i = 0; i < n; i++) tr.in(limbs + i);
     if (c->keygen) { std::vector<int64_t> o(n); for (size_t i = 0; i < n; i++) o[i] = off(limbs + i); c->mr.bits_or_limbs_to_num(o.data(), n, (int)limb_bits); }
-    *out = t_inner_product(c, a.data(), b.data(), n); return kg_done(c, "h2w_limbs_to_num");
+    *out = t_inner_product(c, a.data(), b.data(), n); tr.out(out); tr.done(); return kg_done(c, "h2w_limbs_to_num");
 }
-int h2w_check_less_than_safe(h2w_ctx *c, const h2w_assigned_t *a, uint64_t b) { if (!check(c, "h2w_check_less_than_safe")) return -1; if (c->keygen) c->mr.check_less_than_safe(off(a), b); t_check_less_than_safe(c, *a, b); return kg_done(c, "h2w_check_less_than_safe"); }
-int h2w_range_check(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits) { if (!check(c, "h2w_range_check")) return -1; if (c->keygen) c->mr.range_check(off(a), range_bits); t_range_check(c, *a, range_bits); return kg_done(c, "h2w_range_check"); }
+int h2w_check_less_than_safe(h2w_ctx *c, const h2w_assigned_t *a, uint64_t b) { if (!check(c, "h2w_check_less_than_safe")) return -1; TrRec tr(c, TR_CLT_SAFE, 0, b); tr.in(a); if (c->keygen) c->mr.check_less_than_safe(off(a), b); t_check_less_than_safe(c, *a, b); tr.done(); return kg_done(c, "h2w_check_less_than_safe"); }
+int h2w_range_check(h2w_ctx *c, const h2w_assigned_t *a, size_t range_bits) { if (!check(c, "h2w_range_check")) return -1; TrRec tr(c, TR_RANGE_CHECK, 0, range_bits); tr.in(a); if (c->keygen) c->mr.range_check(off(a), range_bits); t_range_check(c, *a, range_bits); tr.done(); return kg_done(c, "h2w_range_check"); }
 int h2w_constrain_equal(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b) { if (!check(c, "h2w_constrain_equal")) return -1; if (c->keygen) c->mr.equal(off(a), off(b)); return 0; }
 
 // ---------------------------------------------------------------- ContextWrapper::{push_context, pop_context} (util/context_wrapper.rs:28-34)
 int h2w_push_context(h2w_ctx *c, const char *name) {
     if (!check(c, "h2w_push_context") || !name) return -1;
+    if (c->trace) { TrRec tr(c, TR_SCOPE_PUSH, 0, c->trace->names.size()); c->trace->names.push_back(name); tr.done(); }
     int ch = -1;
     for (int k : c->nodes[c->cur].children) if (c->nodes[k].name == name) { ch = k; break; }
     if (ch < 0) { ch = (int)c->nodes.size(); c->nodes.push_back(h2w_ctx::Node{c->cur, name, 0, {}}); c->nodes[c->cur].children.push_back(ch); }
@@ -302,6 +360,7 @@ int h2w_push_context(h2w_ctx *c, const char *name) {
 int h2w_pop_context(h2w_ctx *c) {
     if (!check(c, "h2w_pop_context")) return -1;
     if (c->enter.empty()) return fail(c, "h2w_pop_context: no open context");
+    if (c->trace) { TrRec tr(c, TR_SCOPE_POP); tr.done(); }
     c->nodes[c->cur].cells += c->ncells - c->enter.back(); c->enter.pop_back(); c->cur = c->nodes[c->cur].parent; return 0;
 }
 // collapsed-stack dump "a;b;c <inclusive cells>\n" (util/context_tree.rs:132-152 writes own counts; inclusive is what the SVG frames show)
@@ -322,9 +381,10 @@ static inline bool gl_canon(const fr_t &v) { return fits64(v) && v.l[0] < GL_P; 
 int h2w_gl_load_constant(h2w_ctx *c, uint64_t a, h2w_assigned_t *out) { fr_t v = fr_from_u64(a); return h2w_load_constant(c, &v, out); }
 int h2w_gl_load_witness(h2w_ctx *c, uint64_t a, h2w_assigned_t *out) {
     if (!check(c, "h2w_gl_load_witness")) return -1;
+    TrRec tr(c, TR_GL_WITNESS); tr.tag_required("h2w_gl_load_witness");
     if (c->keygen) c->mr.gl_load_witness();
     uint64_t off = c->ncells; rec(c, T_LOADW, a, 0, 0, 0);
-    *out = mk(c, fr_from_u64(a), off); return kg_done(c, "h2w_gl_load_witness");
+    *out = mk(c, fr_from_u64(a), off); tr.out(out); tr.done(); return kg_done(c, "h2w_gl_load_witness");
 }
 // record for the 61-cell reduce tail of an arbitrary (< 2^128) value; returns remainder wire
 static int gl_reduce_impl(h2w_ctx *c, const fr_t &v, h2w_assigned_t *out) {
@@ -336,7 +396,7 @@ static int gl_reduce_impl(h2w_ctx *c, const fr_t &v, h2w_assigned_t *out) {
     *out = mk(c, fr_from_u64(r), off + (uint64_t)nl);    // remainder = second load_witness cell
     return 0;
 }
-int h2w_gl_reduce(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) { if (!check(c, "h2w_gl_reduce")) return -1; if (c->keygen && !(a->value.l[2] | a->value.l[3])) c->mr.gl_reduce(off(a)); if (gl_reduce_impl(c, a->value, out) != 0) return -1; return kg_done(c, "h2w_gl_reduce"); }
+int h2w_gl_reduce(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) { if (!check(c, "h2w_gl_reduce")) return -1; TrRec tr(c, TR_GL_REDUCE); tr.in(a); if (c->keygen && !(a->value.l[2] | a->value.l[3])) c->mr.gl_reduce(off(a)); if (gl_reduce_impl(c, a->value, out) != 0) return -1; tr.out(out); tr.done(); return kg_done(c, "h2w_gl_reduce"); }
 static int glop(h2w_ctx *c, int t, uint64_t A, uint64_t B, uint64_t C, h2w_assigned_t *out) {
     uint64_t r = gl_reduce128((u128)A * B + C);
     uint64_t off = c->ncells; rec(c, t, A, B, C, 0);
@@ -345,17 +405,19 @@ static int glop(h2w_ctx *c, int t, uint64_t A, uint64_t B, uint64_t C, h2w_assig
     return 0;
 }
 #define GL_ARGS2(fn) if (!check(c, fn)) return -1; if (!fits64(a->value) || !fits64(b->value)) return fail(c, std::string(fn) + ": operand is not a 64-bit Goldilocks wire")
-int h2w_gl_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_add"); if (c->keygen) c->mr.gl_reduce(c->mr.add(MR::EX(off(a)), MR::EX(off(b)))); glop(c, T_GLOP, b->value.l[0], 1, a->value.l[0], out); return kg_done(c, "h2w_gl_add"); }
-int h2w_gl_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_mul"); if (c->keygen) c->mr.gl_reduce(c->mr.mul(MR::EX(off(a)), MR::EX(off(b)))); glop(c, T_GLOP, a->value.l[0], b->value.l[0], 0, out); return kg_done(c, "h2w_gl_mul"); }
+int h2w_gl_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_add"); TrRec tr(c, TR_GLOP, T_GLOP); tr.in(b); tr.lit(1); tr.in(a); if (c->keygen) c->mr.gl_reduce(c->mr.add(MR::EX(off(a)), MR::EX(off(b)))); glop(c, T_GLOP, b->value.l[0], 1, a->value.l[0], out); tr.out(out); tr.done(); return kg_done(c, "h2w_gl_add"); }
+int h2w_gl_mul(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) { GL_ARGS2("h2w_gl_mul"); TrRec tr(c, TR_GLOP, T_GLOP); tr.in(a); tr.in(b); tr.lit(0); if (c->keygen) c->mr.gl_reduce(c->mr.mul(MR::EX(off(a)), MR::EX(off(b)))); glop(c, T_GLOP, a->value.l[0], b->value.l[0], 0, out); tr.out(out); tr.done(); return kg_done(c, "h2w_gl_mul"); }
 int h2w_gl_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     GL_ARGS2("h2w_gl_sub");
+    TrRec tr(c, TR_GLOP, T_KB_GLOP); tr.in(b); tr.lit(GL_NEG_ONE); tr.in(a);
     if (c->keygen) { const int64_t m1 = c->mr.load_constant(fr_from_u64(GL_NEG_ONE)); c->mr.gl_reduce(c->mr.mul_add(MR::EX(off(b)), MR::EX(m1), MR::EX(off(a)))); }
-    glop(c, T_KB_GLOP, b->value.l[0], GL_NEG_ONE, a->value.l[0], out); return kg_done(c, "h2w_gl_sub");
+    glop(c, T_KB_GLOP, b->value.l[0], GL_NEG_ONE, a->value.l[0], out); tr.out(out); tr.done(); return kg_done(c, "h2w_gl_sub");
 }
 int h2w_gl_mul_add(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, const h2w_assigned_t *cc, h2w_assigned_t *out) {
     GL_ARGS2("h2w_gl_mul_add"); if (!fits64(cc->value)) return fail(c, "h2w_gl_mul_add: operand is not a 64-bit Goldilocks wire");
+    TrRec tr(c, TR_GLOP, T_GLOP); tr.in(a); tr.in(b); tr.in(cc);
     if (c->keygen) c->mr.gl_reduce(c->mr.mul_add(MR::EX(off(a)), MR::EX(off(b)), MR::EX(off(cc))));
-    glop(c, T_GLOP, a->value.l[0], b->value.l[0], cc->value.l[0], out); return kg_done(c, "h2w_gl_mul_add");
+    glop(c, T_GLOP, a->value.l[0], b->value.l[0], cc->value.l[0], out); tr.out(out); tr.done(); return kg_done(c, "h2w_gl_mul_add");
 }
 int h2w_gl_div(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w_assigned_t *out) {
     GL_ARGS2("h2w_gl_div");
@@ -363,9 +425,11 @@ int h2w_gl_div(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b, h2w
     if (b->value.l[0] == 0) return fail(c, "h2w_gl_div: division by zero (reference asserts, base.rs:379)");
     uint64_t res = gl_mul(a->value.l[0], gl_inv(b->value.l[0]));
     h2w_assigned_t rw, prod;
+    if (c->trace) { if (!a->has_cell || !b->has_cell) c->trace->fail("h2w_gl_div: an operand is not a cell"); c->trace->pending = TraceTag{2, 0, 0, a->offset, b->offset}; }      // the hint a / b is the library's (base.rs:382)
     h2w_gl_load_witness(c, res, &rw);
+    TrRec tr(c, TR_GLOP, T_GLOP); tr.in(b); tr.in(&rw); tr.lit(0);
     if (c->keygen) { const int64_t pr = c->mr.gl_reduce(c->mr.mul(MR::EX(off(b)), MR::EX(off(&rw)))); c->mr.equal(off(a), pr); }      // gl.assert_equal(a, b * res)
-    glop(c, T_GLOP, b->value.l[0], res, 0, &prod);
+    glop(c, T_GLOP, b->value.l[0], res, 0, &prod); tr.out(&prod); tr.done();
     *out = rw; return kg_done(c, "h2w_gl_div");
 }
 // GoldilocksChip::mul_sub (base.rs:332-343): mul_no_reduce, sub_no_reduce (= prod + c*(p-1) with a NEG_ONE constant cell), reduce: 70 cells
@@ -377,8 +441,10 @@ int h2w_gl_mul_sub(h2w_ctx *c, const h2w_assigned_t *a, const h2w_assigned_t *b,
     }
     h2w_assigned_t prod, neg_one, diff; const h2w_fr_t m1 = fr_from_u64(GL_NEG_ONE);
     if (h2w_mul(c, a, b, &prod) != 0 || h2w_load_constant(c, &m1, &neg_one) != 0 || h2w_mul_add(c, cc, &neg_one, &prod, &diff) != 0) return -1;
+    TrRec tr(c, TR_GL_REDUCE); tr.in(&diff);
     if (c->keygen) c->mr.gl_reduce(off(&diff));
     if (gl_reduce_impl(c, diff.value, out) != 0) return -1;
+    tr.out(out); tr.done();
     return kg_done(c, "h2w_gl_mul_sub");
 }
 // GoldilocksChip::neg (base.rs:234-238): load_neg_one, mul
@@ -399,6 +465,33 @@ int h2w_gl_inv(h2w_ctx *c, const h2w_assigned_t *a, h2w_assigned_t *out) {
     if (!check(c, "h2w_gl_inv")) return -1;
     h2w_assigned_t one; h2w_gl_load_constant(c, 1, &one);
     return h2w_gl_div(c, &one, a, out);
+}
+
+// GoldilocksQuadExtChip::inv's hint (extension.rs:320-340: `let inverse = a.value().inverse()` then load_witness of its two components): the inverse
+// is computed here, so that a traced run (trace.h) can recompute it for another proof.  The caller goes on with mul(a, out) and its assert_equal.
+int h2w_gl_ext_inv_witness(h2w_ctx *c, const h2w_assigned_t a[2], h2w_assigned_t out[2]) {
+    if (!check(c, "h2w_gl_ext_inv_witness")) return -1;
+    if (!gl_canon(a[0].value) || !gl_canon(a[1].value)) return fail(c, "h2w_gl_ext_inv_witness: non-canonical Goldilocks wire");
+    gle_t av; av.c[0] = a[0].value.l[0]; av.c[1] = a[1].value.l[0];
+    if (av.c[0] == 0 && av.c[1] == 0) return fail(c, "h2w_gl_ext_inv_witness: inverse of zero (reference panics, extension.rs:327)");
+    const gle_t iv = gle_inv(av);
+    for (int k = 0; k < 2; k++) {
+        if (c->trace) { if (!a[0].has_cell || !a[1].has_cell) c->trace->fail("h2w_gl_ext_inv_witness: an operand is not a cell"); c->trace->pending = TraceTag{3 + k, 0, 0, a[0].offset, a[1].offset}; }
+        if (h2w_gl_load_witness(c, iv.c[k], out + k) != 0) return -1;
+    }
+    return 0;
+}
+// ---- trace mode (trace.h)
+int h2w_ctx_trace_begin(h2w_ctx *c) {
+    if (!check(c, "h2w_ctx_trace_begin")) return -1;
+    if (c->ncells != 0 || c->trace) return fail(c, "h2w_ctx_trace_begin: the context must be fresh");
+    c->trace = new Trace(); return 0;
+}
+int h2w_trace_input(h2w_ctx *c, uint64_t word, uint32_t n_words) {
+    if (!check(c, "h2w_trace_input")) return -1;
+    if (!c->trace) return 0;                       // not tracing: nothing to tag
+    if (n_words != 1 && n_words != 4) return fail(c, "h2w_trace_input: a proof value is 1 word (a Goldilocks element) or 4 (a BN254 hash)");
+    c->trace->pending = TraceTag{1, word, n_words, 0, 0}; return 0;
 }
 
 // ---------------------------------------------------------------- keygen-side metadata of the eager context (witness_gen_only == 0)
@@ -466,3 +559,9 @@ int h2w_ctx_download(h2w_ctx *c, uint64_t first, uint64_t count, h2w_fr_t *host_
 }
 
 }  // extern "C"
+
+namespace h2w {
+Trace *ctx_trace(h2w_ctx *c) { return c ? c->trace : nullptr; }
+int ctx_lookup_bits(const h2w_ctx *c) { return c->L; }
+uint64_t ctx_num_cells(const h2w_ctx *c) { return c->ncells; }
+}

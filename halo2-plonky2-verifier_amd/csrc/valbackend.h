@@ -50,6 +50,8 @@ struct ValCfg {
 template <class Sink> struct ValBackend {
     typedef uint64_t Gl; typedef uint64_t Bool; typedef fr_t Fr; typedef u128 Big;
     static constexpr bool kCoopPoseidon = Sink::kCoop;
+    static constexpr bool kHintOps = false;                    // hints (GoldilocksChip::div, ext inv) are computed by the chips on this backend's values
+    HF Gl gl_div(Gl, Gl) { return 0; } HF void ext_inv_witness(const Gl *, Gl *) {}
     static constexpr bool kSplitOnly = Sink::kSplitOnly;       // the backend only ever runs strands whose Merkle proofs are other strands
     static constexpr bool kDevSponge = Sink::kDevSponge;       // the Fiat-Shamir sponge is kept by the sink (device prologue wavefront)
     static constexpr bool kBnUnits = Sink::kBnUnits;           // every PoseidonBN254 permutation of this backend is a unit handled by the sink

@@ -139,6 +139,9 @@ int h2w_gl_mul_sub(h2w_ctx *, const h2w_assigned_t *a, const h2w_assigned_t *b, 
 int h2w_gl_neg(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                              /* :234-238 (1 + 65) */
 int h2w_gl_square(h2w_ctx *, const h2w_assigned_t *a, h2w_assigned_t *out);                           /* :401-404 (65) */
 int h2w_gl_exp_power_of_2(h2w_ctx *, const h2w_assigned_t *base, size_t power_log, h2w_assigned_t *out); /* :433-445 (65 * power_log) */
+/* The hint of GoldilocksQuadExtChip::inv (field/goldilocks/extension.rs:320-340: `a.value().inverse()` loaded as two witnesses, 56 cells at
+ * lookup_bits 21): the inverse of a[0] + a[1] X is computed inside; the caller goes on with mul(a, out) and the assert_equal.  Error if a == 0 (:327). */
+int h2w_gl_ext_inv_witness(h2w_ctx *, const h2w_assigned_t a[2], h2w_assigned_t out[2]);
 
 /* ------------------------------------------------------------------ 2b. the reference's higher chips over the eager boundary
  * (host side above the C-ABI: csrc/chips.h + csrc/verifier.h instantiated on a backend that only calls the functions above).
@@ -154,6 +157,24 @@ int h2w_chip_merkle_verify(h2w_ctx *, const h2w_poseidon_consts_t *, int hash_mo
                            const h2w_assigned_t *index_bits, size_t n_bits, const h2w_assigned_t *cap_index,
                            const h2w_assigned_t *cap, size_t n_cap, const h2w_assigned_t *siblings, size_t n_sib);                               /* merkle/mod.rs:57-78 */
 int h2w_chip_verify_stark(h2w_ctx *, const h2w_shape_t *, const h2w_poseidon_consts_t *, const uint64_t *proof_words);                         /* stark/mod.rs:483-508 */
+
+/* ------------------------------------------------------------------ 2d. record and replay: the operator API served at GPU speed
+ * A context in trace mode records the tape of ONE run driven through nothing but the level-1 / level-2 calls above (for the reference: its unchanged
+ * chips over the NativeChip shim); h2w_plan_from_trace lowers the tape to a device program, and h2w_fri_witness_batch replays it on any batch of proofs
+ * of the same shape - bit-identical to running the calls on each of them.  What makes a run replayable:
+ *   - control flow does not depend on values (true of the reference's gadgets: SURVEY 7);
+ *   - a value that depends on the proof enters as a TAGGED proof word: h2w_trace_input(ctx, word, n) just before the h2w_load_witness /
+ *     h2w_gl_load_witness / h2w_load_constant / h2w_gl_load_constant that loads it (n = 1: a Goldilocks element, 4: a BN254 hash);
+ *   - hints are computed by the library: the two sites where the reference reads AssignedValue::value() for one (base.rs:382, extension.rs:327)
+ *     are h2w_gl_div and h2w_gl_ext_inv_witness;  an untagged witness is an error at h2w_plan_from_trace.
+ * parallel_scopes: names of h2w_push_context scopes whose instances do not depend on one another (the reference's #[count] scopes
+ * "verify_query_round", fri/mod.rs:488-501, and "verify_proof_to_cap_with_cap_index", merkle/mod.rs:57-78): each instance becomes a lane of the
+ * device program.  The library VERIFIES the claim on the tape (an instance may read what its enclosing scopes computed before it and nothing else;
+ * nothing outside reads what it computes) and fails otherwise.  The plan supports h2w_plan_num_cells / _proof_words / _num_records /
+ * _workspace_bytes / _status, h2w_fri_witness_batch and h2w_plan_free. */
+int h2w_ctx_trace_begin(h2w_ctx *);                                   /* on a fresh context */
+int h2w_trace_input(h2w_ctx *, uint64_t word, uint32_t n_words);      /* no-op on a context that is not tracing */
+h2w_plan *h2w_plan_from_trace(h2w_ctx *, uint64_t proof_words, const char *const *parallel_scopes, size_t n_scopes, int device_id);
 
 /* ------------------------------------------------------------------ advice hand-off (eager contexts) */
 /* Expands all pending records on the GPU; *dev_ptr receives a device pointer to num_cells*32 bytes
