@@ -558,7 +558,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             if (nunits && passes != 1) {
                 // the values of the paths: one wavefront per path (rowperm.h: a path's 18 permutations in ~1.1 ms instead of 2.5) while the chip has a SIMD
                 // for (nearly) every path; four lanes per path (coop.h bn_values: a sixth of the instructions per path) beyond that
-                const bool rows = p->values_form ? p->values_form == 2 : (uint64_t)nunits * nkinds <= 2048;
+                const bool rows = p->values_form ? p->values_form == 2 : (uint64_t)nunits * nkinds <= 2560;
                 const uint32_t upq = unit_slot_of(p);
                 const uint64_t nval = (uint64_t)nunits * upq * (BN_PARTIAL_ROUNDS * 3);
                 if (rows) {

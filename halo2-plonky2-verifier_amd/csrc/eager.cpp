@@ -16,6 +16,7 @@
 #include "common.h"
 #include "keygen.h"
 #include "trace.h"
+#include "host_fr.h"
 #include "poseidon_tables.h"
 
 namespace h2w {
@@ -30,7 +31,7 @@ using namespace h2w;
 
 struct h2w_ctx {
     int L, witness_gen_only, device; uint32_t id;
-    TemplateTable tt; FrParams P;
+    TemplateTable tt; FrParams P; HostFr H;
     std::vector<uint64_t> meta; std::vector<rec_t> recs; std::vector<fr_t> pool;
     uint64_t ncells = 0;
     bool zero_set = false; uint64_t zero_off = 0;
@@ -66,23 +67,30 @@ struct TrRec {
 inline bool fits64(const fr_t &v) { return (v.l[1] | v.l[2] | v.l[3]) == 0; }
 inline Av mk(h2w_ctx *c, const fr_t &v, uint64_t off) { Av a; a.value = v; a.offset = off; a.ctx_id = c->id; a.has_cell = 1; return a; }
 
+// the host side of a context streams into three vectors (a PoseidonBN254 proof: 350 MB of literal cells), grown by doubling.  (Asking for huge pages
+// on the fresh memory - first-touch faults are a large part of a level-1 call - was tried and lost: with THP in madvise mode the fault compacts
+// synchronously, 218 -> 466 ns per h2w_mul.)
+template <class T> inline void room(std::vector<T> &v) { if (v.size() == v.capacity()) v.reserve(v.capacity() ? v.capacity() * 2 : (size_t)1 << 16); }
 inline void lit(h2w_ctx *c, const fr_t &v) {
     if (!c->recs.empty() && meta_tmpl(c->meta.back()) == T_LITERAL && c->recs.back().a + c->recs.back().b == c->pool.size() &&
         meta_off(c->meta.back()) + c->recs.back().b == c->ncells) {
         c->recs.back().b++;
     } else {
+        room(c->meta); room(c->recs);
         c->meta.push_back(meta_pack(T_LITERAL, c->ncells));
         c->recs.push_back(rec_t{(uint64_t)c->pool.size(), 1, 0, 0});
     }
+    room(c->pool);
     c->pool.push_back(v); c->ncells++;
 }
 inline void rec(h2w_ctx *c, int t, uint64_t a, uint64_t b, uint64_t cc, uint64_t d) {
+    room(c->meta); room(c->recs);
     c->meta.push_back(meta_pack((uint32_t)t, c->ncells));
     c->recs.push_back(rec_t{a, b, cc, d});
     c->ncells += (uint64_t)c->tt.ncells(t);
 }
 inline void cell(h2w_ctx *c, const fr_t &v) { if (fits64(v)) rec(c, T_CONST1, v.l[0], 0, 0, 0); else lit(c, v); }
-inline fr_t fmul(h2w_ctx *c, const fr_t &a, const fr_t &b) { return fr_mul(a, b, c->P); }
+inline fr_t fmul(h2w_ctx *c, const fr_t &a, const fr_t &b) { return host_fr_mul(a, b, c->H); }      // (host_fr.h: the product that bounds the eager level)
 
 fr_t inv_cached(h2w_ctx *c, const fr_t &x) {  // Assigned::Rational(1, x) -> x^{-1}
     const size_t N = 96;
@@ -203,7 +211,7 @@ h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id) {
     if (lookup_bits < 2 || lookup_bits > 28) { set_error("h2w_ctx_new: lookup_bits out of range [2,28]"); return nullptr; }
     h2w_ctx *c = new h2w_ctx(lookup_bits);
     c->L = lookup_bits; c->witness_gen_only = witness_gen_only; c->device = device_id; c->id = g_next_ctx_id++;
-    c->P = fr_params_init();
+    c->P = fr_params_init(); { static const HostFr hf = host_fr_init(); c->H = hf; }
     c->keygen = witness_gen_only == 0; c->mr.L = lookup_bits;
     return c;
 }
