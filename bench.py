@@ -517,15 +517,20 @@ def _main():
             rplan = api.Plan.from_trace(tctx, plan.proof_words, device_id=local_rank)
             t3 = time.perf_counter()
             tctx.close()
-            rB = B
+            # a replay launch is as long as its longest lane (the prologue's sponge: ~100 ms of one wavefront whatever the batch), so its rate is the batch:
+            # as many proofs per launch as fit (the step's B proofs, repeated)
+            free_now, _ = torch.cuda.mem_get_info(dev)
+            per_proof = rplan.num_cells * 32 + rplan.workspace_bytes(64) // 64
+            rB = int(max(B, min(192, (free_now - 12e9) // per_proof)))
+            rproofs = my_proofs.repeat((rB + B - 1) // B)[:rB * plan.proof_words].contiguous()
             radv = torch.empty(rB * rplan.num_cells * 32, dtype=torch.uint8, device=dev)
             rws = torch.empty(rplan.workspace_bytes(rB), dtype=torch.uint8, device=dev)
             rst = streams[0].cuda_stream
-            rplan.run(my_proofs.data_ptr(), rB, radv.data_ptr(), rws.data_ptr(), rst); torch.cuda.synchronize()      # warm-up
+            rplan.run(rproofs.data_ptr(), rB, radv.data_ptr(), rws.data_ptr(), rst); torch.cuda.synchronize()      # warm-up
             rn = 4
             t4 = time.perf_counter()
             for _ in range(rn):
-                rplan.run(my_proofs.data_ptr(), rB, radv.data_ptr(), rws.data_ptr(), rst)
+                rplan.run(rproofs.data_ptr(), rB, radv.data_ptr(), rws.data_ptr(), rst)
             torch.cuda.synchronize()
             rt = time.perf_counter() - t4
             assert rplan.status(rws.data_ptr(), rB, rst) == [0] * rB
@@ -537,7 +542,7 @@ def _main():
                                "value": rplan.num_cells * rB * rn / rt, "unit": "cells/s", "proofs_per_launch": rB, "launches": rn, "ms_per_launch": rt / rn * 1e3,
                                "trace_seconds": t2 - t1, "lowering_seconds": t3 - t2, "records_per_proof": rplan.num_records, "workspace_GB": rplan.workspace_bytes(rB) / 1e9,
                                "proof_0_equals_primary_path_stream": same}
-            del radv, rws, chk, cws
+            del radv, rws, chk, cws, rproofs
             rplan.close(); torch.cuda.empty_cache()
         except Exception as e:      # the side leg must not take the bench line down
             eager["replay"] = {"error": repr(e)}

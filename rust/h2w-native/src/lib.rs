@@ -120,6 +120,30 @@ impl<F: BigPrimeField> Context<F> {
     pub fn constrain_equal(&mut self, a: &AssignedValue<F>, b: &AssignedValue<F>) { // native.rs:189-192
         ck(unsafe { h2w_constrain_equal(self.h2w, &to_h2w(a), &to_h2w(b)) });
     }
+    // ---- record and replay (include/h2w.h 2d): ONE run of the unchanged chips on this context becomes a plan the GPU replays
+    /// start recording the op tape (on a fresh context)
+    pub fn trace_begin(&mut self) {
+        ck(unsafe { h2w_ctx_trace_begin(self.h2w) });
+    }
+    /// the next `load_witness` / `load_constant` takes its value from proof word(s) `[word, word + n_words)` of the flat layout (witness/mod.rs:48-225);
+    /// a no-op unless the context is tracing
+    pub fn trace_input(&mut self, word: u64, n_words: u32) {
+        ck(unsafe { h2w_trace_input(self.h2w, word, n_words) });
+    }
+    /// the hint of `GoldilocksQuadExtChip::inv` (extension.rs:320-340), computed inside the library
+    pub fn gl_ext_inv_witness(&mut self, a: &[AssignedValue<F>; 2]) -> [AssignedValue<F>; 2] {
+        let (ain, mut out) = ([to_h2w(&a[0]), to_h2w(&a[1])], [H2wAssigned::default(); 2]);
+        ck(unsafe { h2w_gl_ext_inv_witness(self.h2w, ain.as_ptr(), out.as_mut_ptr()) });
+        [from_h2w(&out[0]), from_h2w(&out[1])]
+    }
+    /// the recorded run as a plan for `h2w_fri_witness_batch`; `parallel_scopes`: the `#[count]` scopes whose instances are independent
+    /// (`"verify_query_round"`, fri/mod.rs:488-501; `"verify_proof_to_cap_with_cap_index"`, merkle/mod.rs:57-78) - checked by the library
+    pub fn plan_from_trace(&mut self, proof_words: u64, parallel_scopes: &[&std::ffi::CStr], device_id: i32) -> *mut H2wPlan {
+        let names: Vec<*const std::os::raw::c_char> = parallel_scopes.iter().map(|s| s.as_ptr()).collect();
+        let plan = unsafe { h2w_plan_from_trace(self.h2w, proof_words, names.as_ptr(), names.len(), device_id) };
+        if plan.is_null() { panic!("{}", unsafe { std::ffi::CStr::from_ptr(h2w_last_error()) }.to_string_lossy()); }
+        plan
+    }
     /// the advice stream (canonical `Fr`), expanded on the GPU and copied back
     pub fn advice_values(&mut self) -> Vec<F> {
         let n = self.advice.len();

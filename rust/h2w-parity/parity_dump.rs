@@ -134,8 +134,9 @@ fn out_dir(sub: &str) -> String {
 }
 
 /// `log2(num_rows)`: 3 is the reference's own test size (no FRI fold step, empty Merkle paths); 7 and up exercise the fold loop
-/// (`fri/mod.rs:403-438`), which no reference test reaches.
-const DEGREE_BITS: &[usize] = &[3, 7];
+/// (`fri/mod.rs:403-438`), which no reference test reaches: 7 has one arity-16 step, 11 has TWO (the BASELINE arity with a second, shorter
+/// Merkle path per query and `x <- x^16` applied between them: `fri/mod.rs:433-437`).
+const DEGREE_BITS: &[usize] = &[3, 7, 11];
 
 #[test]
 fn parity_dump_bn254() {
