@@ -517,32 +517,37 @@ def _main():
             rplan = api.Plan.from_trace(tctx, plan.proof_words, device_id=local_rank)
             t3 = time.perf_counter()
             tctx.close()
-            # a replay launch is as long as its longest lane (the prologue's sponge: ~100 ms of one wavefront whatever the batch), so its rate is the batch:
-            # as many proofs per launch as fit (the step's B proofs, repeated)
+            # a replay launch is as long as its longest lane (the prologue's sponge: ~100 ms of ONE wavefront whatever the batch), so its rate is the batch and the
+            # launches in flight: two streams (the root kernel of one launch is two wavefronts: it runs beside the Merkle lanes of the other), as many proofs as fit
             free_now, _ = torch.cuda.mem_get_info(dev)
             per_proof = rplan.num_cells * 32 + rplan.workspace_bytes(64) // 64
-            rB = int(max(B, min(192, (free_now - 12e9) // per_proof)))
+            rS = 2
+            rB = int(max(8, min(96, (free_now - 12e9) // (rS * per_proof))))
             rproofs = my_proofs.repeat((rB + B - 1) // B)[:rB * plan.proof_words].contiguous()
-            radv = torch.empty(rB * rplan.num_cells * 32, dtype=torch.uint8, device=dev)
-            rws = torch.empty(rplan.workspace_bytes(rB), dtype=torch.uint8, device=dev)
-            rst = streams[0].cuda_stream
-            rplan.run(rproofs.data_ptr(), rB, radv.data_ptr(), rws.data_ptr(), rst); torch.cuda.synchronize()      # warm-up
-            rn = 4
+            radvs = [torch.empty(rB * rplan.num_cells * 32, dtype=torch.uint8, device=dev) for _ in range(rS)]
+            rwss = [torch.empty(rplan.workspace_bytes(rB), dtype=torch.uint8, device=dev) for _ in range(rS)]
+            while len(streams) < rS:
+                streams.append(torch.cuda.Stream(device=dev))
+            for j in range(rS):
+                rplan.run(rproofs.data_ptr(), rB, radvs[j].data_ptr(), rwss[j].data_ptr(), streams[j].cuda_stream)      # warm-up
+            torch.cuda.synchronize()
+            rn = 6
             t4 = time.perf_counter()
-            for _ in range(rn):
-                rplan.run(rproofs.data_ptr(), rB, radv.data_ptr(), rws.data_ptr(), rst)
+            for j in range(rn):
+                rplan.run(rproofs.data_ptr(), rB, radvs[j % rS].data_ptr(), rwss[j % rS].data_ptr(), streams[j % rS].cuda_stream)
             torch.cuda.synchronize()
             rt = time.perf_counter() - t4
+            radv, rws, rst = radvs[0], rwss[0], streams[0].cuda_stream
             assert rplan.status(rws.data_ptr(), rB, rst) == [0] * rB
             # the replayed stream of proof 0 against the primary path's stream of the same proof (both are oracle-checked in tests/; this ties the two here)
             chk = torch.empty(plan.num_cells * 32, dtype=torch.uint8, device=dev); cws = torch.empty(plan.workspace_bytes(1), dtype=torch.uint8, device=dev)
             plan.run(my_proofs.data_ptr(), 1, chk.data_ptr(), cws.data_ptr(), rst); torch.cuda.synchronize()
             same = bool(torch.equal(chk, radv[:plan.num_cells * 32]))
             eager["replay"] = {"what": "h2w_chip_verify_stark recorded ONCE in trace mode (one proof, level-1 / level-2 calls only), lowered by h2w_plan_from_trace, replayed by h2w_fri_witness_batch on the step's proofs",
-                               "value": rplan.num_cells * rB * rn / rt, "unit": "cells/s", "proofs_per_launch": rB, "launches": rn, "ms_per_launch": rt / rn * 1e3,
+                               "value": rplan.num_cells * rB * rn / rt, "unit": "cells/s", "proofs_per_launch": rB, "launches": rn, "launches_in_flight": rS, "ms_per_launch": rt / rn * 1e3,
                                "trace_seconds": t2 - t1, "lowering_seconds": t3 - t2, "records_per_proof": rplan.num_records, "workspace_GB": rplan.workspace_bytes(rB) / 1e9,
                                "proof_0_equals_primary_path_stream": same}
-            del radv, rws, chk, cws, rproofs
+            del radv, rws, chk, cws, rproofs, radvs, rwss
             rplan.close(); torch.cuda.empty_cache()
         except Exception as e:      # the side leg must not take the bench line down
             eager["replay"] = {"error": repr(e)}

@@ -9,7 +9,7 @@ CONFIGS = {"cfg1": (10, 4, 1), "cfg2": (16, 28, 2), "cfg3": (20, 28, 1), "cfg5":
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="cfg3"); ap.add_argument("--hash", default="bn254"); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--config", default="cfg3"); ap.add_argument("--hash", default="bn254"); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--reps", type=int, default=2); ap.add_argument("--streams", type=int, default=1)
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -28,6 +28,17 @@ def main():
     proofs = torch.from_numpy(host).cuda()
     adv = torch.empty(a.batch * plan.num_cells * 32, dtype=torch.uint8, device="cuda"); ws = torch.zeros(plan.workspace_bytes(a.batch), dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
+    if a.streams > 1:      # launches in flight: the root kernel of one (two wavefronts) runs beside the other's Merkle lanes
+        strs = [torch.cuda.Stream() for _ in range(a.streams)]
+        advs = [adv] + [torch.empty_like(adv) for _ in range(a.streams - 1)]; wss = [ws] + [torch.zeros_like(ws) for _ in range(a.streams - 1)]
+        for j in range(a.streams):
+            plan.run(proofs.data_ptr(), a.batch, advs[j].data_ptr(), wss[j].data_ptr(), strs[j].cuda_stream)
+        torch.cuda.synchronize(); t = time.perf_counter(); nl = 3 * a.streams
+        for j in range(nl):
+            plan.run(proofs.data_ptr(), a.batch, advs[j % a.streams].data_ptr(), wss[j % a.streams].data_ptr(), strs[j % a.streams].cuda_stream)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print(json.dumps({"config": a.config, "hash": a.hash, "batch": a.batch, "streams": a.streams, "launches": nl, "ms_per_launch": round(dt / nl * 1e3, 2), "G_cells_per_s": round(plan.num_cells * a.batch * nl / dt / 1e9, 2)}))
+        del advs, wss
     ms = []
     for i in range(a.reps + 1):
         torch.cuda.synchronize(); t = time.perf_counter()
