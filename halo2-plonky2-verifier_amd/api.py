@@ -23,6 +23,10 @@ class Context:
             raise H2WError("h2w_ctx_new: " + last_error())
         self.lookup_bits = lookup_bits
 
+    def reset(self):
+        """The context as new, its host memory kept (h2w_ctx_reset): for the next proof's run."""
+        _ck(self.L.h2w_ctx_reset(self.p), "h2w_ctx_reset")
+
     def trace_begin(self):
         """Record the op tape of this context's run (h2w_ctx_trace_begin; Plan.from_trace turns it into a replayable plan)."""
         _ck(self.L.h2w_ctx_trace_begin(self.p), "h2w_ctx_trace_begin")

@@ -225,6 +225,17 @@ void h2w_ctx_free(h2w_ctx *c) {
     c->dt.free();
     delete c;
 }
+// The context as new, its host memory kept: the next proof's run appends into vectors that are already sized and mapped (a PoseidonBN254 proof streams 350 MB of
+// literal cells through them; first-touch page faults and reallocation copies are a third of a level-1 call on a fresh context).  Handles of the old run are void.
+int h2w_ctx_reset(h2w_ctx *c) {
+    if (!check(c, "h2w_ctx_reset")) return -1;
+    c->meta.clear(); c->recs.clear(); c->pool.clear(); c->ncells = 0; c->zero_set = false; c->zero_off = 0; c->err = 0;
+    c->id = g_next_ctx_id++;                      // stale handles are recognisably another context's
+    { MetaRecorder fresh; fresh.L = c->mr.L; c->mr = fresh; }
+    c->nodes.assign(1, h2w_ctx::Node{-1, "all", 0, {}}); c->cur = 0; c->enter.clear();
+    delete c->trace; c->trace = nullptr;
+    return 0;
+}
 uint64_t h2w_num_cells(const h2w_ctx *c) { return c ? c->ncells : 0; }
 int h2w_ctx_error(const h2w_ctx *c) { return c ? c->err : 1; }
 

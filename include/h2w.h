@@ -93,6 +93,7 @@ int         h2w_poseidon_published(h2w_poseidon_consts_t *out);
  * requested (h2w_ctx_advice_device / h2w_ctx_download). */
 h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id);   /* base_test().k(k): lookup_bits = k-1 */
 void     h2w_ctx_free(h2w_ctx *);
+int      h2w_ctx_reset(h2w_ctx *);                                              /* the context as new, its host memory kept (the next proof's run does not fault its pages in again) */
 uint64_t h2w_num_cells(const h2w_ctx *);                                        /* util/context_wrapper.rs:24-26 */
 int      h2w_ctx_error(const h2w_ctx *);                                        /* sticky error flag of the context */
 /* scoped cell counters: what the reference's #[count] proc-macro (macro/src/lib.rs:9-61) drives through

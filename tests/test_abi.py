@@ -126,6 +126,25 @@ def test_comm_entry_points_fail_loudly_without_a_device(h2w):
     L.h2w_comm_free(None)
 
 
+def test_context_reset_is_a_fresh_context_with_its_memory(h2w, h2w_api):
+    """h2w_ctx_reset: cell count, scopes, the cached load_zero cell, keygen lists and the trace are gone; a handle of the old run is not a cell of the new one."""
+    ctx = h2w_api.Context(21, False, 0)
+    chip = h2w_api.GoldilocksChip(h2w_api.NativeChip(ctx))
+    ctx.push_context("a"); a = chip.load_constant(5); b = chip.mul(a, a); ctx.pop_context()
+    n1, g1 = ctx.num_cells(), len(ctx.gate_cells())
+    assert n1 > 0 and g1 > 0
+    ctx.reset()
+    assert ctx.num_cells() == 0 and len(ctx.gate_cells()) == 0 and ctx.cell_counts() == {"all": 0}
+    ctx.push_context("a"); a2 = chip.load_constant(5); chip.mul(a2, a2); ctx.pop_context()
+    assert ctx.num_cells() == n1 and len(ctx.gate_cells()) == g1
+    ctx.reset(); ctx.trace_begin()
+    chip.load_constant(7)
+    with pytest.raises(h2w.H2WError):        # an operand of the previous run: another context id
+        chip.mul(a2, a2)
+        h2w_api.Plan.from_trace(ctx, 4)
+    ctx.close()
+
+
 def test_product_library_has_no_experiment_switches(h2w):
     """No experiment switches exist in the sources any more (round 1 shipped wrong-output kernel variants behind getenv): kernel variants are
     local patches / compile-time flags built as a separately named library by tools/experiments/variant.sh, and the library the tests, smoke()

@@ -134,7 +134,14 @@ def test_fibonacci_stark_through_eager_boundary(h2w, h2w_api, oracle, consts, mo
         assert oracle.verify_stark(octx, osh, ko, proof) == 0
         assert ctx.num_cells() == octx.num_cells()
         assert ctx.advice_bytes() == octx.advice_bytes()
-        ctx.close(); octx.close()
+        # the same context for the next proof (h2w_ctx_reset: its host memory is kept, everything else is as new)
+        proof2 = oracle.synth_proof(osh, 177 + d); octx2 = oracle.Ctx(21)
+        ctx.reset()
+        assert ctx.num_cells() == 0
+        assert h2w.lib().h2w_chip_verify_stark(ctx.p, C.byref(sh), C.byref(kh), proof2) == 0, h2w.last_error()
+        assert oracle.verify_stark(octx2, osh, ko, proof2) == 0
+        assert ctx.advice_bytes() == octx2.advice_bytes()
+        ctx.close(); octx.close(); octx2.close()
 
 
 def test_permutations_reproduce_published_known_answers(h2w, h2w_api, oracle, published):
