@@ -183,7 +183,7 @@ def _main():
     ap.add_argument("--streams", type=int, default=4, help="launches in flight, each on its own HIP stream with its own advice / workspace buffers")
     ap.add_argument("--launches-per-step", type=int, default=12)
     ap.add_argument("--lookup-bits", type=int, default=21)
-    ap.add_argument("--advice-cap-gb", type=float, default=250.0, help="upper bound on the advice buffers of all launches in flight (the stream count is reduced to fit)")
+    ap.add_argument("--advice-cap-gb", type=float, default=262.0, help="upper bound on the advice buffers of all launches in flight (the stream count is reduced to fit)")
     ap.add_argument("--calib", type=int, default=3, help="isolated launches after the timed region (one at a time, chain kernel on the caller's stream) for the per-kernel roofline numbers")
     ap.add_argument("--proofs", default="valid", choices=["valid", "random"], help="synthetic inputs: valid FRI instances generated on the GPU by the ingest rank (h2w_prove_fri_batch, SURVEY 8d variant A) or uniform random words (variant B)")
     ap.add_argument("--shard-queries", action="store_true", help="N > 1: shard the (proof, query) units of the SAME proofs over the ranks (strong scaling; default for cfg5)")

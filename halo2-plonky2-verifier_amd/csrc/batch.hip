@@ -556,9 +556,11 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
             p->passes_of[p->n_batches % h2w_plan::EV_RING] = passes;
             if (nunits && passes == 1) { if (cm.starts) hipLaunchKernelGGL(k_merkle_bn_fused<true>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_bn_fused<false>, sgrid, dim3(QUAD_BLOCK), 0, cstream, A); }
             if (nunits && passes != 1) {
-                // the values of the paths: one wavefront per path (rowperm.h: a path's 18 permutations in ~1.1 ms instead of 2.5) while the chip has a SIMD
-                // for (nearly) every path; four lanes per path (coop.h bn_values: a sixth of the instructions per path) beyond that
-                const bool rows = p->values_form ? p->values_form == 2 : (uint64_t)nunits * nkinds <= 2560;
+                // the values of the paths: one wavefront per path (rowperm.h: a path's 18 permutations in 1.3 ms instead of 2.6) for a launch of a few proofs - the form for
+                // one proof's latency; four lanes per path (coop.h bn_values: a sixth of the instructions per path) beyond that: alone on the chip the wavefront form
+                // wins up to ~2,500 paths (profiles/r04_values_forms.jsonl), but a caller with several launches in flight pays for its instructions (cfg 1 pipelined,
+                // 1,024 paths per launch: 160 G cells/s against 175-190), so the default switches early and H2W_OPT_VALUES_FORM = 2 is the caller's to set
+                const bool rows = p->values_form ? p->values_form == 2 : (uint64_t)nunits * nkinds <= 784;
                 const uint32_t upq = unit_slot_of(p);
                 const uint64_t nval = (uint64_t)nunits * upq * (BN_PARTIAL_ROUNDS * 3);
                 if (rows) {

@@ -338,8 +338,9 @@ int h2w_advice_to_montgomery(void *cells_dev, uint64_t n_cells, void *stream);
 #define H2W_OPT_CHAIN_PASSES 3
 /* H2W_OPT_VALUES_FORM (PoseidonBN254 caps, two-pass paths): how the values pass walks a path.  1: four lanes per path (a Montgomery product on one
  * lane); 2: one wavefront per path, a product spread over the 16 lanes of a row, one 29-bit limb per lane (a path in less than half the time, six
- * times the instructions per path: right while there is a SIMD for nearly every path).  0 (default): 2 for launches of at most 2560 paths of this
- * rank (13 proofs of 2^20 rows x 28 queries: measured crossover, profiles/r04_values_forms.jsonl), else 1.  The cells are the same either way. */
+ * times the instructions per path: right while there is a SIMD for nearly every path).  0 (default): 2 for launches of at most 784 paths of this
+ * rank (4 proofs of 2^20 rows x 28 queries), else 1: alone on the chip form 2 wins up to ~2,500 paths (profiles/r04_values_forms.jsonl), with other launches
+ * in flight its instructions are not free - a caller that runs one launch at a time sets 2.  The cells are the same either way. */
 #define H2W_OPT_VALUES_FORM 4
 int h2w_plan_configure(h2w_plan *, int option, int value);
 /* Kernel timing of a batch call, in ms, from HIP events the library records on the streams it launches on:
