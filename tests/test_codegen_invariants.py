@@ -87,3 +87,37 @@ def test_expand_fast_has_no_scratch(tmp_path):
         lo, hi = _function(lines, variant)
         assert _count(lines, lo, hi, "scratch_") == 0
         assert _count(lines, lo, hi, "flat_store") == 0      # every cell store is a global_store
+
+
+def test_row_cooperative_values_pass_round_loops(tmp_path):
+    """k_merkle_bn_values_row (glue.hip; rowfr.h / rowperm.h): the partial-round loop is three lane-cooperative products (3 x 29 multiply-adds) without a scratch or
+    flat access and without a vector-memory wait (its only memory traffic are the three S-box stores); its table entries are read a round ahead (the LDS reads
+    stand at the top of the loop); it stays near the instruction count its 1.3 ms correspond to."""
+    glue = _asm("glue.hip", tmp_path)
+    lo, hi = _function(glue, "_ZN3h2w7RowSink12permute_unit")
+    loops = list(_loops(glue, lo, hi))
+    partial = [(a, b) for a, b in loops if 85 <= _count(glue, a, b, "v_mad_u64_u32") <= 90]
+    assert partial, "partial-round loop (three products of 29 multiply-adds) not found"
+    a, b = min(partial, key=lambda ab: ab[1] - ab[0])
+    _clean(glue, a, b, "row-cooperative partial-round loop")
+    assert _count(glue, a, b, "global_load") == 0
+    assert not [l for l in glue[a:b + 1] if re.search(r"s_waitcnt.*vmcnt\(0\)", l)], "the row-cooperative partial round waits for its S-box stores"
+    n = sum(1 for l in glue[a:b + 1] if re.match(r"^\s+[a-z]", l))
+    assert n <= 540, f"partial round grew to {n} instructions"
+    first_mad = next(i for i in range(a, b + 1) if re.match(r"^\s+v_mad_u64_u32", glue[i]))
+    assert _count(glue, a, first_mad, "ds_read") >= 6, "the round's table entries are no longer read ahead of its first product"
+    full = [(c, d) for c, d in loops if (d < a or c > b) and 195 <= _count(glue, c, d, "v_mad_u64_u32") <= 215]
+    assert full, "full-round loop (seven products) not found"
+    for c, d in full:
+        _clean(glue, c, d, "row-cooperative full-round loop")
+
+
+def test_replay_interpreter_reads_its_tape_with_scalar_loads(tmp_path):
+    """k_replay (replay.hip): the tape pointer must stay uniform - without the readfirstlane on the template's fields every tape word was a vector load behind the
+    record stores in flight (2.5 us per op) and every branch a lane mask; operands come from LDS (the ring and the pools), far ones through the one out-of-line path."""
+    lines = _asm("replay.hip", tmp_path)
+    lo, hi = _function(lines, "_ZN3h2w8k_replay")
+    end = next(i for i in range(lo, len(lines)) if "s_endpgm" in lines[i])
+    assert _count(lines, lo, end, "s_load_dword") >= 50, "the interpreter no longer reads its tape with scalar loads"
+    assert _count(lines, lo, end, "global_load") + _count(lines, lo, end, "flat_load") <= 40, "vector loads crept into the interpreter (tape words? operands outside LDS?)"
+    assert _count(lines, lo, end, "ds_read") >= 50
