@@ -8,7 +8,7 @@ the timed region starts.  `--config cfg1|cfg2|cfg5`, `--hash gl` select the othe
 One *launch* = one h2w_fri_witness_batch call (the whole hot path: prologue strands, query glue strands, Merkle strands,
 expansion) over `--batch` proofs.  Launches go round-robin over `--streams` HIP streams with their own advice / workspace
 buffers, so the latency-bound strands of one launch overlap the HBM-bound kernels of another.  One *step* = `--launches-per-step`
-launches (default 12): a step is sized to ~0.15 s so that the timed region lasts seconds whatever `--steps` is, and `--warmup`
+launches (default 24): a step is sized to ~0.22 s so that the timed region lasts seconds whatever `--steps` is (the driver's --steps 20: 4.5 s), and `--warmup`
 steps (at least one) touch every stream's buffers before the clock starts.
 
 N > 1 (`--gpus N`; launched by torch.distributed.run, or spawned by this script itself when WORLD_SIZE is not set): one rank
@@ -181,7 +181,7 @@ def _main():
     ap.add_argument("--hash", default="bn254", choices=["bn254", "gl"])
     ap.add_argument("--batch", type=int, default=0, help="proofs per launch (0 = auto: ~58 GB of advice per launch)")
     ap.add_argument("--streams", type=int, default=4, help="launches in flight, each on its own HIP stream with its own advice / workspace buffers")
-    ap.add_argument("--launches-per-step", type=int, default=12)
+    ap.add_argument("--launches-per-step", type=int, default=24)
     ap.add_argument("--lookup-bits", type=int, default=21)
     ap.add_argument("--advice-cap-gb", type=float, default=262.0, help="upper bound on the advice buffers of all launches in flight (the stream count is reduced to fit)")
     ap.add_argument("--calib", type=int, default=3, help="isolated launches after the timed region (one at a time, chain kernel on the caller's stream) for the per-kernel roofline numbers")

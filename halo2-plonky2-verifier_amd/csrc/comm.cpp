@@ -19,6 +19,7 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional: what RCCL itself says the communicator spans
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -34,6 +35,7 @@ Rccl &rccl() {
         r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
         r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
         r.ok = r.GetUniqueId && r.CommInitRank && r.Broadcast && r.AllGather && r.CommDestroy && r.GetErrorString;
     });
@@ -79,7 +81,12 @@ void h2w_comm_free(h2w_comm *c) {
     delete c;
 }
 int h2w_comm_rank(const h2w_comm *c) { return c ? c->rank : -1; }
-int h2w_comm_world(const h2w_comm *c) { return c ? c->world : 0; }
+int h2w_comm_world(const h2w_comm *c) {      // the ranks RCCL counts in the communicator (ncclCommCount), not the number it was asked for
+    if (!c) return 0;
+    int n = c->world;
+    if (c->comm && rccl().ok && rccl().CommCount && rccl().CommCount(c->comm, &n) != ncclSuccess) n = -1;
+    return n;
+}
 int h2w_comm_broadcast_proofs(h2w_comm *c, uint64_t *proofs_dev, uint64_t n_words, int root, void *stream) {
     if (!c || !proofs_dev || root < 0 || root >= c->world) { set_error("h2w_comm_broadcast_proofs: bad argument"); return -1; }
     if (n_words == 0) return 0;
