@@ -120,6 +120,10 @@ impl<F: BigPrimeField> Context<F> {
     pub fn constrain_equal(&mut self, a: &AssignedValue<F>, b: &AssignedValue<F>) { // native.rs:189-192
         ck(unsafe { h2w_constrain_equal(self.h2w, &to_h2w(a), &to_h2w(b)) });
     }
+    /// the context as new, its host memory kept: for the next proof through the same context
+    pub fn reset(&mut self) {
+        ck(unsafe { h2w_ctx_reset(self.h2w) });
+    }
     // ---- record and replay (include/h2w.h 2d): ONE run of the unchanged chips on this context becomes a plan the GPU replays
     /// start recording the op tape (on a fresh context)
     pub fn trace_begin(&mut self) {
