@@ -129,7 +129,7 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_glp_emit(BatchArgs 
 template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(BatchArgs A) {
     typedef CoopSinkT<COLS, true, 0> Sink; typedef ValBackend<Sink> CoopB;
     __builtin_amdgcn_s_setprio(3);
-    stage_glp_consts(A.consts, threadIdx.x, 64);
+    stage_glp_consts<true>(A.consts, threadIdx.x, 64);
     int p, q;
     if (!own_unit_at(A, blockIdx.x, p, q)) return;
     const int sq = q == 0 ? 0 : 1;
@@ -316,8 +316,12 @@ h2w_plan *h2w_plan_compile(const h2w_shape_t *shape, const h2w_poseidon_consts_t
         }
         H2W_HIP(hipMalloc((void **)&pl->d_st, sizeof(StrandTable)));
         H2W_HIP(hipMemcpy(pl->d_st, &pl->st, sizeof(StrandTable), hipMemcpyHostToDevice));
-        H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t)));
-        H2W_HIP(hipMemcpy(pl->d_consts, consts, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
+        {   // the constants, and behind them the derived tables of the values phase (coop.h glp_aux_tables)
+            std::vector<uint64_t> aux(GLP_AUX_WORDS); glp_aux_tables(*consts, aux.data());
+            H2W_HIP(hipMalloc((void **)&pl->d_consts, sizeof(h2w_poseidon_consts_t) + aux.size() * sizeof(uint64_t)));
+            H2W_HIP(hipMemcpy(pl->d_consts, consts, sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
+            H2W_HIP(hipMemcpy(pl->d_consts + 1, aux.data(), aux.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        }
         std::vector<uint16_t> nc(T_MAX, 0); for (size_t i = 0; i < pl->tt.info.size(); i++) nc[i] = pl->tt.info[i].ncells;
         H2W_HIP(hipMalloc((void **)&pl->d_ncells, nc.size() * sizeof(uint16_t)));
         H2W_HIP(hipMemcpy(pl->d_ncells, nc.data(), nc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));

@@ -47,9 +47,32 @@ __shared__ uint64_t s_glp_m[SPONGE_WIDTH * SPONGE_WIDTH];              // MDS as
 typedef __attribute__((address_space(3))) uint64_t lds64_t;
 constexpr int KO_ARC = 0, KO_CIRC = 360, KO_DIAG = 372, KO_FIRST = 384, KO_PRC = 396, KO_INIT = 418, KO_WHAT = 539, KO_VS = 781;
 static_assert(KO_VS + 242 == GLP_CONST_WORDS, "Goldilocks constant block layout");
-__device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k, int tid, int nthreads) {
+// Derived tables of the values phase (glperm.h: the partial rounds with their row sums unrolled into per-round accumulators), computed once on the host
+// (glp_aux_tables) and kept behind the constants on the device:
+//   C[k][j] (XO_C + 22 k + j): what round k's S-box output a_k adds to s0 of round j + 1:  sum_i w_hat[j][i] v[k][i] for k < j, circ0 + diag0 for k = j, 0 for k > j
+//   G[r][j] (XO_G + 22 (r - 1) + j): what element r (1..11) of the state BEFORE mds_partial_layer_init adds to round j's row sum:  sum_c w_hat[j][c] init[r-1][c-1]
+constexpr int XO_C = 0, XO_G = N_PARTIAL_ROUNDS * N_PARTIAL_ROUNDS, GLP_AUX_WORDS = XO_G + 11 * N_PARTIAL_ROUNDS;
+__shared__ uint64_t s_glp_x[GLP_AUX_WORDS];
+inline void glp_aux_tables(const h2w_poseidon_consts_t &c, uint64_t *aux) {
+    for (int k = 0; k < N_PARTIAL_ROUNDS; k++)
+        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) {
+            uint64_t a = 0;
+            if (k == j) a = gl_add(c.mds_circ[0] % GL_P, c.mds_diag[0] % GL_P);
+            else if (k < j) for (int i = 0; i < 11; i++) a = gl_muladd(c.fast_partial_round_w_hats[j][i] % GL_P, c.fast_partial_round_vs[k][i] % GL_P, a);
+            aux[XO_C + N_PARTIAL_ROUNDS * k + j] = a;
+        }
+    for (int r = 0; r < 11; r++)
+        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) {
+            uint64_t a = 0;
+            for (int i = 0; i < 11; i++) a = gl_muladd(c.fast_partial_round_w_hats[j][i] % GL_P, c.fast_partial_round_initial_matrix[r][i] % GL_P, a);
+            aux[XO_G + N_PARTIAL_ROUNDS * r + j] = a;
+        }
+}
+// AUX: also the derived tables (the kernels of the values phase; they sit behind the struct: h2w_plan's device copy)
+template <bool AUX = false> __device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k, int tid, int nthreads) {
     const uint64_t *src = reinterpret_cast<const uint64_t *>(k);
     for (int i = tid; i < GLP_CONST_WORDS; i += nthreads) s_glp_k[i] = g_load_u64(src + i);
+    if constexpr (AUX) { const uint64_t *ax = reinterpret_cast<const uint64_t *>(k + 1); for (int i = tid; i < GLP_AUX_WORDS; i += nthreads) s_glp_x[i] = g_load_u64(ax + i); }
     for (int i = tid; i < SPONGE_WIDTH * SPONGE_WIDTH; i += nthreads) {
         const int r = i / SPONGE_WIDTH, j = i % SPONGE_WIDTH; int d = j - r; if (d < 0) d += SPONGE_WIDTH;
         const uint64_t c = g_load_u64(src + KO_CIRC + d);
@@ -57,9 +80,10 @@ __device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k,
     }
     __syncthreads();
 }
-// plonky2's MDS entries are tiny (<= 41): a row is then two 64-bit sums of 32-bit halves and ONE reduction (the prover's trick, prover.hip)
+// plonky2's MDS entries are tiny (<= 41): a row is then two 64-bit sums of 32-bit halves and ONE reduction (the prover's trick, prover.hip).
+// Below 2^26 each, a dense entry circ + diag is below 2^27 and a sum of 12 terms plus a constant word below 2^63 (glq_reduce96's precondition, glperm.h).
 inline bool glp_small_mds(const h2w_poseidon_consts_t &k) {
-    for (int i = 0; i < SPONGE_WIDTH; i++) if (k.mds_circ[i] >= (1ull << 27) || k.mds_diag[i] >= (1ull << 27)) return false;
+    for (int i = 0; i < SPONGE_WIDTH; i++) if (k.mds_circ[i] >= (1ull << 26) || k.mds_diag[i] >= (1ull << 26)) return false;
     return true;
 }
 
@@ -97,8 +121,11 @@ __device__ __forceinline__ uint64_t glz_add2(uint64_t a, uint64_t b) {     // an
 }
 // Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES: lane l < 12 holds state element l and
 // returns its element of the output.  K: the constant block in LDS, M: the dense MDS rows (stage_glp_consts).
-__device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64_t *M, int l, bool small) {
+__device__ __noinline__ uint64_t glp_permute_lanes_v1(uint64_t x, lds64_t *K, lds64_t *M, int l, bool small) {
     const int lc = l < SPONGE_WIDTH ? l : SPONGE_WIDTH - 1, lm = lc > 0 ? lc - 1 : 0;
+#ifdef H2W_EXP_GLP_STUB      // experiment (tools/experiments/variant.sh): what the values phase costs WITHOUT its permutations - the values are garbage
+    return x + K[KO_ARC + lc];
+#endif
     // LDS reads are ~110 cycles each for a wavefront with nothing else to run, and a read that is used where it stands is waited for there (a third
     // of this function's time: profiles/r03_pmc_values_b1_after.txt): this lane's row of the dense MDS matrix sits in registers for all eight full
     // rounds (small entries: one dword each), and every round's table words are read a round ahead.
@@ -159,15 +186,18 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
     for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) { const int rc = HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + i; full_round(rc, i + 1 < HALF_N_FULL_ROUNDS ? rc + 1 : rc); }
     return x >= GL_P ? x - GL_P : x;
 }
+}      // namespace h2w
+#include "glperm.h"
+namespace h2w {
 constexpr int GLP_LIST_WORDS = 1 + SPONGE_WIDTH;            // one listed permutation: {index of its first record, input state}
 
 // VALPH: the values phase of a strand (see the top of the file); false: the record-emitting permutation (k_glp_emit)
 template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
     static constexpr bool kCoop = true, kSplitOnly = false, kBnUnits = false, kDevSponge = VALPH; static constexpr int kHashMode = HASH_MODE;
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint16_t *ncells; int lane; ColPolicy<COLS> cc;
-    lds64_t *lk = nullptr, *la = nullptr, *lb = nullptr, *lm = nullptr;      // s_glp_k, s_glp_a, s_glp_b, s_glp_m of the running kernel (set by bind_lds)
+    lds64_t *lk = nullptr, *la = nullptr, *lb = nullptr, *lm = nullptr, *lx = nullptr;      // s_glp_k, s_glp_a, s_glp_b, s_glp_m (s_glp_x: values phase) of the running kernel (set by bind_lds)
     uint64_t *glp = nullptr; uint32_t glp_slot = 0; bool small_mds = false;   // values phase: this proof's permutation list, the next slot of this strand
-    __device__ __forceinline__ void bind_lds() { lk = (lds64_t *)s_glp_k; la = (lds64_t *)s_glp_a; lb = (lds64_t *)s_glp_b; lm = (lds64_t *)s_glp_m; }
+    __device__ __forceinline__ void bind_lds() { lk = (lds64_t *)s_glp_k; la = (lds64_t *)s_glp_a; lb = (lds64_t *)s_glp_b; lm = (lds64_t *)s_glp_m; if constexpr (VALPH) lx = (lds64_t *)s_glp_x; }
     bool emit = true;            // false: values only (a sharded run computes every prologue for its challenges, but only the owning rank emits it)
     __device__ __forceinline__ void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         if (lane == 0 && emit) g_store_rec(recs + nrec, a, b, c, d);
@@ -222,7 +252,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         const uint64_t up = __shfl_up(sx, 1, 64), w = lane == 0 ? nrec : up;
         if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
         glp_slot++;
-        sx = glp_permute_lanes(sx, lk, lm, lane, small_mds);
+        sx = glp_permute_lanes(sx, lk, lm, lx, lane, small_mds);
         nrec += GLP_RECS;
         cell_off += perm_cell_count();
     }
@@ -256,7 +286,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
             for (int i = 0; i < SPONGE_WIDTH; i++) { if (lane == i + 1) w = st[i]; if (lane == i) x = st[i]; }
             if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
             glp_slot++;
-            x = glp_permute_lanes(x, lk, lm, lane, small_mds);
+            x = glp_permute_lanes(x, lk, lm, lx, lane, small_mds);
 #pragma unroll
             for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = readlane64(x, i);
             nrec += GLP_RECS;

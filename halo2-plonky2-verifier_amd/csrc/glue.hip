@@ -110,7 +110,7 @@ template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) v
 template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_prologue_values(BatchArgs A) {
     typedef CoopSinkT<COLS, true> Sink; typedef ValBackend<Sink> CoopB;
     __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
-    stage_glp_consts(A.consts, threadIdx.x, 64);
+    stage_glp_consts<true>(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
     Sink sink; coop_sink_init(sink, A, p, -1); sink.nrec = 0; sink.cell_off = 0; sink.glp_slot = 0;
     sink.emit = own_prologue(A, p);

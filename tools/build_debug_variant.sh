@@ -10,5 +10,5 @@ mkdir -p ../build_$name
 hipcc $FLAGS -c batch.hip -o ../build_$name/batch.o
 hipcc $FLAGS -c glue.hip -o ../build_$name/glue.o
 hipcc $FLAGS -c expand.hip -o ../build_$name/expand.o
-hipcc --offload-arch=gfx950 -shared -fPIC ../build_$name/expand.o ../build/eager.o ../build_$name/batch.o ../build_$name/glue.o ../build/chipbatch.o ../build/abi_backend.o ../build/prover.o ../build/comm.o -ldl -o ../libh2w_$name.so
+hipcc --offload-arch=gfx950 -shared -fPIC ../build_$name/expand.o ../build/eager.o ../build_$name/batch.o ../build_$name/glue.o ../build/chipbatch.o ../build/abi_backend.o ../build/prover.o ../build/comm.o ../build/replay.o -ldl -o ../libh2w_$name.so
 echo "built $(realpath ../libh2w_$name.so)"
