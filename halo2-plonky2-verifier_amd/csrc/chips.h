@@ -32,27 +32,48 @@ inline void fri_tab_build(FriTab &t, int lde_bits) {
 }
 enum { PRE_NONE = 0, PRE_A = 1, PRE_B = 2 };
 
+// A small array that is indexed with run-time indices WITHOUT being addressed: an element is picked by a chain of selects over constant indices.
+// One access through a run-time offset keeps a WHOLE local object in scratch memory (the compiler splits an object into registers only when every
+// access to it has a constant offset) - and with the Verifier in memory so are the backend and the sink it points to: every counter the strand kernels
+// bump was a scratch round trip behind their record stores (round 4: 2.4 k cycles around every permutation of the prologue).
+template <class T, int N> struct SelArr {
+    T v[N];
+    HF T operator[](int i) const {
+        T r = v[0];
+#pragma unroll
+        for (int j = 1; j < N; j++) { const T e = v[j]; r = i == j ? e : r; }      // (every element READ, then picked: a load under the condition is merged with its neighbours into one load at a selected offset - a run-time offset again)
+        return r;
+    }
+    HF void set(int i, T x) {
+#pragma unroll
+        for (int j = 0; j < N; j++) v[j] = i == j ? x : v[j];
+    }
+};
 // shape-derived quantities (plonky2 FriParams)
 struct Derived {
-    int lde_bits, n_steps, arity[MAX_STEPS], final_poly_len, cap_size, n_oracles, oracle_polys[3];
+    int lde_bits, n_steps; SelArr<int, MAX_STEPS> arity; int final_poly_len, cap_size, n_oracles; SelArr<int, 3> oracle_polys;
 };
 HF Derived derive_shape(const h2w_shape_t &s) {
     Derived d; d.lde_bits = s.degree_bits + s.rate_bits; d.n_steps = 0;
     int db = s.degree_bits;
-    while (db > s.final_poly_bits && db + s.rate_bits - s.arity_bits >= s.cap_height && d.n_steps < MAX_STEPS) { d.arity[d.n_steps++] = s.arity_bits; db -= s.arity_bits; }
+#pragma unroll
+    for (int i = 0; i < MAX_STEPS; i++) {      // (once the condition fails it stays failed: db no longer changes)
+        const bool more = db > s.final_poly_bits && db + s.rate_bits - s.arity_bits >= s.cap_height;
+        d.arity.v[i] = more ? s.arity_bits : 0;
+        if (more) { d.n_steps = i + 1; db -= s.arity_bits; }
+    }
     d.final_poly_len = 1 << db; d.cap_size = 1 << s.cap_height;
-    d.n_oracles = 0; d.oracle_polys[d.n_oracles++] = s.n_cols;
-    if (s.n_perm_z > 0) d.oracle_polys[d.n_oracles++] = s.n_perm_z;
-    d.oracle_polys[d.n_oracles++] = s.n_quotient;
+    d.oracle_polys.v[0] = s.n_cols; d.oracle_polys.v[1] = s.n_perm_z > 0 ? s.n_perm_z : s.n_quotient; d.oracle_polys.v[2] = s.n_perm_z > 0 ? s.n_quotient : 0;
+    d.n_oracles = s.n_perm_z > 0 ? 3 : 2;
     return d;
 }
 // Flat proof layout = WitnessChip load order (witness/mod.rs:236-294); every hash is 4 u64 words
 // (GL mode: 4 field elements; BN254 mode: canonical LE limbs of the Fr hash, poseidon_bn254/hash.rs:19-21).
 struct ProofLayout {
     uint64_t trace_cap, quotient_cap, openings, perm_cap, pow_witness, final_poly, commit_caps, queries, query_words, pis, total;
-    uint64_t init_off[3];            // within a query: start of oracle o (evals then siblings)
-    uint64_t step_off[MAX_STEPS];    // within a query: start of fold step i (evals then siblings)
-    int step_sibs[MAX_STEPS], init_sibs;
+    SelArr<uint64_t, 3> init_off;            // within a query: start of oracle o (evals then siblings)
+    SelArr<uint64_t, MAX_STEPS> step_off;    // within a query: start of fold step i (evals then siblings)
+    SelArr<int, MAX_STEPS> step_sibs; int init_sibs;
 };
 HF ProofLayout proof_layout(const h2w_shape_t &s, const Derived &d) {
     ProofLayout L; uint64_t w = 0;
@@ -65,9 +86,16 @@ HF ProofLayout proof_layout(const h2w_shape_t &s, const Derived &d) {
     L.commit_caps = w; w += (uint64_t)d.n_steps * d.cap_size * 4;
     L.queries = w;
     uint64_t q = 0; L.init_sibs = d.lde_bits - s.cap_height;
-    for (int o = 0; o < d.n_oracles; o++) { L.init_off[o] = q; q += (uint64_t)d.oracle_polys[o] + (uint64_t)L.init_sibs * 4; }
+#pragma unroll
+    for (int o = 0; o < 3; o++) { L.init_off.v[o] = q; if (o < d.n_oracles) q += (uint64_t)d.oracle_polys.v[o] + (uint64_t)L.init_sibs * 4; }
     int bits = d.lde_bits;
-    for (int i = 0; i < d.n_steps; i++) { bits -= d.arity[i]; L.step_off[i] = q; L.step_sibs[i] = bits - s.cap_height; q += (2ull << d.arity[i]) + (uint64_t)L.step_sibs[i] * 4; }
+#pragma unroll
+    for (int i = 0; i < MAX_STEPS; i++) {      // (constant indices: see SelArr)
+        const bool on = i < d.n_steps;
+        if (on) bits -= d.arity.v[i];
+        L.step_off.v[i] = q; L.step_sibs.v[i] = on ? bits - s.cap_height : 0;
+        if (on) q += (2ull << d.arity.v[i]) + (uint64_t)L.step_sibs.v[i] * 4;
+    }
     L.query_words = q; w += q * (uint64_t)s.num_queries;
     L.pis = w; w += (uint64_t)s.n_pis; L.total = w;
     return L;

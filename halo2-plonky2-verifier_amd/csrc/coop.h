@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "valbackend.h"
 #include "bntab.h"
+#include "glptab.h"
 
 namespace h2w {
 
@@ -44,30 +45,10 @@ __shared__ uint64_t s_glp_m[SPONGE_WIDTH * SPONGE_WIDTH];              // MDS as
 // from a non-kernel function through llvm.amdgcn.lds.offset.table - a GLOBAL load of the offset at every use, i.e. a vmcnt(0) wait
 // for every record store in flight, inside the round loops (that was 60 of the 89 us of a permutation).  A kernel knows the
 // addresses at compile time and passes them down.
+__shared__ uint64_t s_glp_x[GLP_AUX_WORDS];                             // the derived tables of the partial rounds (glptab.h; values phase)
 typedef __attribute__((address_space(3))) uint64_t lds64_t;
 constexpr int KO_ARC = 0, KO_CIRC = 360, KO_DIAG = 372, KO_FIRST = 384, KO_PRC = 396, KO_INIT = 418, KO_WHAT = 539, KO_VS = 781;
 static_assert(KO_VS + 242 == GLP_CONST_WORDS, "Goldilocks constant block layout");
-// Derived tables of the values phase (glperm.h: the partial rounds with their row sums unrolled into per-round accumulators), computed once on the host
-// (glp_aux_tables) and kept behind the constants on the device:
-//   C[k][j] (XO_C + 22 k + j): what round k's S-box output a_k adds to s0 of round j + 1:  sum_i w_hat[j][i] v[k][i] for k < j, circ0 + diag0 for k = j, 0 for k > j
-//   G[r][j] (XO_G + 22 (r - 1) + j): what element r (1..11) of the state BEFORE mds_partial_layer_init adds to round j's row sum:  sum_c w_hat[j][c] init[r-1][c-1]
-constexpr int XO_C = 0, XO_G = N_PARTIAL_ROUNDS * N_PARTIAL_ROUNDS, GLP_AUX_WORDS = XO_G + 11 * N_PARTIAL_ROUNDS;
-__shared__ uint64_t s_glp_x[GLP_AUX_WORDS];
-inline void glp_aux_tables(const h2w_poseidon_consts_t &c, uint64_t *aux) {
-    for (int k = 0; k < N_PARTIAL_ROUNDS; k++)
-        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) {
-            uint64_t a = 0;
-            if (k == j) a = gl_add(c.mds_circ[0] % GL_P, c.mds_diag[0] % GL_P);
-            else if (k < j) for (int i = 0; i < 11; i++) a = gl_muladd(c.fast_partial_round_w_hats[j][i] % GL_P, c.fast_partial_round_vs[k][i] % GL_P, a);
-            aux[XO_C + N_PARTIAL_ROUNDS * k + j] = a;
-        }
-    for (int r = 0; r < 11; r++)
-        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) {
-            uint64_t a = 0;
-            for (int i = 0; i < 11; i++) a = gl_muladd(c.fast_partial_round_w_hats[j][i] % GL_P, c.fast_partial_round_initial_matrix[r][i] % GL_P, a);
-            aux[XO_G + N_PARTIAL_ROUNDS * r + j] = a;
-        }
-}
 // AUX: also the derived tables (the kernels of the values phase; they sit behind the struct: h2w_plan's device copy)
 template <bool AUX = false> __device__ __forceinline__ void stage_glp_consts(const h2w_poseidon_consts_t *k, int tid, int nthreads) {
     const uint64_t *src = reinterpret_cast<const uint64_t *>(k);
@@ -102,89 +83,6 @@ template <int N> __device__ __forceinline__ uint64_t row_shr64(uint64_t v) {    
     const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x110 + N, 0xf, 0xf, true);
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x110 + N, 0xf, 0xf, true);
     return ((uint64_t)hi << 32) | lo;
-}
-// Goldilocks arithmetic of the values phase: operands and results are any 64-bit representatives (x mod p for some x < 2^64), made canonical
-// once, at the end of the permutation - the record-emitting kernels are the ones that need canonical values
-__device__ __forceinline__ uint64_t glz_reduce(u128 x) {      // x (any 128 bits) mod p, up to a multiple of p: 2^64 = 2^32 - 1, 2^96 = -1 (mod p)
-    const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64), hh = hi >> 32, hl = hi & GL_EPS;
-    uint64_t t0 = lo - hh; if (lo < hh) t0 -= GL_EPS;
-    const uint64_t t1 = hl * GL_EPS; uint64_t r = t0 + t1; if (r < t1) r += GL_EPS;
-    return r;
-}
-__device__ __forceinline__ uint64_t glz_mul(uint64_t a, uint64_t b) { return glz_reduce((u128)a * b); }
-__device__ __forceinline__ uint64_t glz_muladd(uint64_t a, uint64_t b, uint64_t c) { return glz_reduce((u128)a * b + c); }
-__device__ __forceinline__ uint64_t glz_add(uint64_t a, uint64_t b) {      // a + b with a canonical or b canonical (the sum wraps at most once, and then r + eps does not wrap again)
-    uint64_t r = a + b; if (r < a) r += GL_EPS; return r;
-}
-__device__ __forceinline__ uint64_t glz_add2(uint64_t a, uint64_t b) {     // any two representatives
-    uint64_t r = a + b; if (r < a) { r += GL_EPS; if (r < GL_EPS) r += GL_EPS; } return r;
-}
-// Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES: lane l < 12 holds state element l and
-// returns its element of the output.  K: the constant block in LDS, M: the dense MDS rows (stage_glp_consts).
-__device__ __noinline__ uint64_t glp_permute_lanes_v1(uint64_t x, lds64_t *K, lds64_t *M, int l, bool small) {
-    const int lc = l < SPONGE_WIDTH ? l : SPONGE_WIDTH - 1, lm = lc > 0 ? lc - 1 : 0;
-#ifdef H2W_EXP_GLP_STUB      // experiment (tools/experiments/variant.sh): what the values phase costs WITHOUT its permutations - the values are garbage
-    return x + K[KO_ARC + lc];
-#endif
-    // LDS reads are ~110 cycles each for a wavefront with nothing else to run, and a read that is used where it stands is waited for there (a third
-    // of this function's time: profiles/r03_pmc_values_b1_after.txt): this lane's row of the dense MDS matrix sits in registers for all eight full
-    // rounds (small entries: one dword each), and every round's table words are read a round ahead.
-    uint32_t mrow[SPONGE_WIDTH];
-    if (small) {
-#pragma unroll
-        for (int j = 0; j < SPONGE_WIDTH; j++) mrow[j] = (uint32_t)M[lc * SPONGE_WIDTH + j];
-    }
-    uint64_t arc_n = K[KO_ARC + lc];
-    auto full_round = [&](int rc, int rc_next) {
-        x = glz_add(x, arc_n);
-        arc_n = K[KO_ARC + SPONGE_WIDTH * rc_next + lc];
-        { const uint64_t x2 = glz_mul(x, x), x3 = glz_mul(x2, x), x4 = glz_mul(x2, x2); x = glz_mul(x3, x4); }      // x^7
-        if (small) {
-            uint64_t lo = 0, hi = 0;
-#pragma unroll
-            for (int j = 0; j < SPONGE_WIDTH; j++) { const uint64_t sj = readlane64(x, j); const uint32_t m = mrow[j]; lo += (uint64_t)m * (uint32_t)sj; hi += (uint64_t)m * (uint32_t)(sj >> 32); }
-            x = glz_reduce((u128)lo + ((u128)hi << 32));
-        } else {
-            uint64_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < SPONGE_WIDTH; j++) acc = glz_muladd(M[lc * SPONGE_WIDTH + j], readlane64(x, j), acc);
-            x = acc;
-        }
-    };
-#pragma unroll 1
-    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) full_round(i, i + 1 < HALF_N_FULL_ROUNDS ? i + 1 : HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS);      // (the last one reads ahead for the second half)
-    x = glz_add(x, K[KO_FIRST + lc]);                                                    // partial_first_constant_layer
-    {   // mds_partial_layer_init: element 0 stays, element c >= 1 = sum_r init[r-1][c-1] s_r
-        uint64_t res = 0;
-#pragma unroll
-        for (int r = 1; r < SPONGE_WIDTH; r++) res = glz_muladd(K[KO_INIT + (r - 1) * 11 + lm], readlane64(x, r), res);
-        x = l == 0 ? x : res;
-    }
-    const uint64_t m00 = K[KO_CIRC] + K[KO_DIAG];
-    uint64_t wh_n = K[KO_WHAT + lm], prc_n = K[KO_PRC], vs_n = K[KO_VS + lm];
-#pragma unroll 11
-    for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
-        // One instruction stream, two jobs per product: lane 0 walks its S-box (x^7 = x^3 x^4), the other lanes form their terms w_hat_i s_i of the
-        // sparse row beside its first product; s0' = s0^7 + c; then lane 0: (circ0 + diag0) s0', lanes i: s_i + v_i s0' in one multiply-add
-        const uint64_t wh = wh_n, prc = prc_n, vs = vs_n;
-        { const int rn = r + 1 < N_PARTIAL_ROUNDS ? r + 1 : r; wh_n = K[KO_WHAT + rn * 11 + lm]; prc_n = K[KO_PRC + rn]; vs_n = K[KO_VS + rn * 11 + lm]; }
-        const uint64_t p1 = glz_mul(x, l == 0 ? x : wh);                                    // lane 0: s0^2 | lanes i: w_hat_i s_i
-        // lane 0 finishes its S-box on its own lane (the others compute along, unused) and only s0' is broadcast: arithmetic on broadcast values is
-        // moved to the scalar unit by the compiler, where a 64 x 64 product is ~35 instructions instead of ~20 - and every instruction of a
-        // wavefront that has its SIMD to itself costs the same four cycles
-        const uint64_t x3 = glz_mul(p1, x), x4 = glz_mul(p1, p1);
-        const uint64_t s0n = readlane64(glz_add(glz_mul(x3, x4), prc), 0);
-        const uint64_t p2 = glz_muladd(l == 0 ? m00 : vs, s0n, l == 0 ? 0 : x);      // lane 0: m00 s0' | lanes i: the new s_i
-        // d = m00 s0' + sum_i w_hat_i s_i: a row scan
-        uint64_t term = l == 0 ? p2 : p1; if (l >= SPONGE_WIDTH) term = 0;
-        term = glz_add2(term, row_shr64<1>(term)); term = glz_add2(term, row_shr64<2>(term));
-        term = glz_add2(term, row_shr64<4>(term)); term = glz_add2(term, row_shr64<8>(term));
-        const uint64_t d = readlane64(term, SPONGE_WIDTH - 1);
-        x = l == 0 ? d : p2;
-    }
-#pragma unroll 1
-    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) { const int rc = HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + i; full_round(rc, i + 1 < HALF_N_FULL_ROUNDS ? rc + 1 : rc); }
-    return x >= GL_P ? x - GL_P : x;
 }
 }      // namespace h2w
 #include "glperm.h"
@@ -223,6 +121,9 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
     // ---- the Fiat-Shamir sponge of the values phase (ChallengerChip, challenger/mod.rs:19-126; overwrite-mode duplex, rate 8): the state
     // lives on the lanes (lane l: element l), the input buffer in LDS; every permutation is listed for k_glp_emit
     uint64_t sx = 0; int sp_in = 0, sp_out = 0; lds64_t *lin = nullptr;
+#ifdef H2W_EXP_GLP_CLOCK
+    long long dbg_cycles = 0, dbg_t[24], dbg_c[24]; int dbg_n = 0, dbg_k = 0, dbg_m[24];
+#endif
     __device__ __forceinline__ void sponge_init() { sx = 0; sp_in = sp_out = 0; lin = (lds64_t *)s_glp_in; }
     __device__ __forceinline__ bool sponge_observe(uint64_t t) { sp_out = 0; if (sp_in >= CH_BUF) return false; lin[sp_in++] = t; return true; }
     template <class WordFn> __device__ __forceinline__ bool sponge_observe_words(const uint64_t *proof, int n, WordFn word) {      // n proof words, one lane each
@@ -249,10 +150,18 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
     }
     __device__ __forceinline__ void sponge_permute() {
         // list the permutation (lane 0: where its records start; lanes 1..12: the input state), then its values
-        const uint64_t up = __shfl_up(sx, 1, 64), w = lane == 0 ? nrec : up;
-        if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
+        // (the list entry is STORED by the permutation, behind its entry: an out-of-line function waits at its entry for every memory operation in
+        // flight, and a store issued just before the call was 2.5 k cycles of every permutation)
+        const uint64_t up = row_shr64<1>(sx), w = lane == 0 ? nrec : up;
+        uint64_t *at = emit && lane < GLP_LIST_WORDS ? glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane : nullptr;
         glp_slot++;
-        sx = glp_permute_lanes(sx, lk, lm, lx, lane, small_mds);
+#ifdef H2W_EXP_GLP_CLOCK      // experiment: the cycles of the strand's sponge permutations (printed by k_prologue_values)
+        const long long c0 = clock64();
+#endif
+        sx = glp_permute_lanes(sx, lk, lm, lx, lane, small_mds, at, w);
+#ifdef H2W_EXP_GLP_CLOCK
+        dbg_cycles += clock64() - c0; dbg_n++;
+#endif
         nrec += GLP_RECS;
         cell_off += perm_cell_count();
     }
@@ -284,9 +193,9 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
             uint64_t w = nrec, x = 0;
 #pragma unroll
             for (int i = 0; i < SPONGE_WIDTH; i++) { if (lane == i + 1) w = st[i]; if (lane == i) x = st[i]; }
-            if (emit && lane < GLP_LIST_WORDS) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane), w);
+            uint64_t *at = emit && lane < GLP_LIST_WORDS ? glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane : nullptr;
             glp_slot++;
-            x = glp_permute_lanes(x, lk, lm, lx, lane, small_mds);
+            x = glp_permute_lanes(x, lk, lm, lx, lane, small_mds, at, w);
 #pragma unroll
             for (int i = 0; i < SPONGE_WIDTH; i++) st[i] = readlane64(x, i);
             nrec += GLP_RECS;

@@ -123,8 +123,14 @@ __device__ __forceinline__ uint64_t glq_mds_small(uint64_t x, const uint32_t (&m
 // Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES.  Lane l < 12 holds state element l and returns its element
 // of the output; the other three rows of the wavefront repeat row 0 (their lanes 12..15, like row 0's, compute along on element 11 and are ignored).
 // K: the constant block in LDS, M: the dense MDS rows, X: the derived tables of the partial rounds (stage_glp_consts<true>).
-__device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64_t *M, lds64_t *X, int l, bool small) {
-    const int l15 = l & 15, lc = l15 < SPONGE_WIDTH ? l15 : SPONGE_WIDTH - 1, lm = lc > 0 ? lc - 1 : 0;
+// list_at / list_word: a word this lane leaves in memory on the way in (the strand's permutation list, coop.h sponge_permute; null: none) - issued here, it
+// has the whole permutation to complete in; issued by the caller, the entry of this function would wait for it.
+__device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64_t *M, lds64_t *X, int l, bool small, uint64_t *list_at = nullptr, uint64_t list_word = 0) {
+    if (list_at) H2W_GSTORE64(reinterpret_cast<unsigned long long *>(list_at), list_word);
+#ifdef H2W_EXP_GLP_STUB      // experiment (tools/experiments/variant.sh): what the values phase costs WITHOUT its permutations - the values are garbage
+    return x + K[KO_ARC + (l & 7)];
+#endif
+    const int l15 = l & 15, lc = l15 < SPONGE_WIDTH ? l15 : SPONGE_WIDTH - 1;
     const bool odd_row = (l >> 4) & 1;
     x = glq_bcast_row0(x);
     // this lane's row of the dense MDS matrix sits in registers for all eight full rounds (small entries: one dword each); every round's table words

@@ -112,12 +112,22 @@ template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) v
     __builtin_amdgcn_s_setprio(3);   // latency-bound serial strand: win issue arbitration against co-resident streaming waves
     stage_glp_consts<true>(A.consts, threadIdx.x, 64);
     const int p = blockIdx.x;
+#ifdef H2W_EXP_GLP_CLOCK
+    const long long k0 = clock64();
+#endif
     Sink sink; coop_sink_init(sink, A, p, -1); sink.nrec = 0; sink.cell_off = 0; sink.glp_slot = 0;
     sink.emit = own_prologue(A, p);
     CoopB be(sink, make_cfg(A, p), true);
     const h2w_shape_t shp = A.shape;      // (a reference into the kernel arguments would put all of them on every lane's stack)
     Verifier<CoopB> V(be, shp, A.consts);
     V.prologue(*reinterpret_cast<ChallengeBlock<CoopB> *>(&A.cbs[p]));
+#ifdef H2W_EXP_GLP_CLOCK
+    if (p == 0 && threadIdx.x == 0) {      // marks (verifier.h prologue): load_proof | caps and alphas | zeta and openings | fri alpha and betas | final poly and pow | query indices | reduced openings
+        const long long total = (long long)clock64() - k0;
+        for (int i = 0; i < sink.dbg_k; i++) printf("mark %d at %lld cycles %lld in %d permutations\n", i, sink.dbg_t[i], sink.dbg_c[i], sink.dbg_m[i]);
+        printf("kernel %lld cycles\n", total);
+    }
+#endif
     if (threadIdx.x == 0) A.status[p] = be.status;
 }
 

@@ -134,10 +134,19 @@ template <class B> struct Verifier {
         i -= s.n_cols; return o + 2ull * (2 * s.n_cols + s.n_perm_z + i);
     }
     // ---- prologue strand
+#if defined(H2W_EXP_GLP_CLOCK) && defined(__HIP_DEVICE_COMPILE__)      // experiment: where the prologue wavefront's cycles go (proof 0, lane 0 prints)
+#define H2W_CLK_MARK(what) do { if constexpr (B::kDevSponge) { if (be.sink.dbg_k < 24) { be.sink.dbg_t[be.sink.dbg_k] = (long long)clock64() - clk0; be.sink.dbg_c[be.sink.dbg_k] = be.sink.dbg_cycles; be.sink.dbg_m[be.sink.dbg_k++] = be.sink.dbg_n; } } } while (0)
+#else
+#define H2W_CLK_MARK(what) do { } while (0)
+#endif
     HF void prologue(ChallengeBlock<B> &cb) {
+#if defined(H2W_EXP_GLP_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
+        const long long clk0 = clock64();
+#endif
         ChallengerChip<B> ch(be, hs, k);
         ch.load_zero_state();                                        // stark/mod.rs:497-499
         load_proof_with_pis();                                       // stark/mod.rs:506
+        H2W_CLK_MARK("load_proof");
         // ChallengerChip::get_stark_challenges (challenger/mod.rs:167-222)
         observe_cap(ch, pl.trace_cap);
         if (s.n_perm_z > 0) {
@@ -146,30 +155,38 @@ template <class B> struct Verifier {
         }
         for (int i = 0; i < s.num_challenges; i++) ch.get_challenge();                               // stark_alphas (:203)
         observe_cap(ch, pl.quotient_cap);
+        H2W_CLK_MARK("caps and alphas");
         const Ex zeta = ch.get_extension_challenge(); cb.zeta = zeta;                               // :206 (what the strand goes on to use is kept in locals: the block is device memory behind a generic reference - every read of it a flat load behind the record stores)
         const int nz = s.n_cols + s.n_perm_z + s.n_quotient, nzn = s.n_cols + s.n_perm_z;
         ch.observe_ext_words(nz, [&](int i) { return zeta_word(i); });                               // observe_openings (:208)
         ch.observe_ext_words(nzn, [&](int i) { return zeta_next_word(i); });
+        H2W_CLK_MARK("zeta and openings");
         // get_fri_challenges (:128-165)
         const Ex fri_alpha = ch.get_extension_challenge(); cb.fri_alpha = fri_alpha;
-        for (int i = 0; i < d.n_steps; i++) { observe_cap(ch, pl.commit_caps + (uint64_t)i * d.cap_size * 4); cb.fri_betas[i] = ch.get_extension_challenge(); }
+        for (int i = 0; i < d.n_steps; i++) { observe_cap(ch, pl.commit_caps + (uint64_t)i * d.cap_size * 4); H2W_CLK_MARK("commit cap observed"); cb.fri_betas[i] = ch.get_extension_challenge(); H2W_CLK_MARK("beta"); }
+        H2W_CLK_MARK("fri alpha and betas");
         ch.observe_ext_words(d.final_poly_len, [&](int i) { return pl.final_poly + 2ull * i; });
         ch.observe_element(be.proof_gl(pl.pow_witness));
         const Gl pow_response = ch.get_challenge(); cb.fri_pow_response = pow_response;
+        H2W_CLK_MARK("final poly and pow");
         for (int i = 0; i < s.num_queries; i++) cb.fri_query_indices[i] = ch.get_challenge();
+        H2W_CLK_MARK("query indices");
         // verify_proof_with_challenges: fri_instance_info (stark/mod.rs:144-200): zeta_next = g * zeta
         { gle_t gv; gv.c[0] = gl_primitive_root_of_unity(s.degree_bits); gv.c[1] = 0; Ex g = ext.load_constant(gv); cb.zeta_next = ext.mul(g, zeta); }
+        H2W_CLK_MARK("zeta_next");
         // FriChip::verify_fri_proof (fri/mod.rs:446-502): PoW (:130-145), from_os_and_alpha (:45-62)
         be.range_check(pow_response, 64 - s.pow_bits);
+        H2W_CLK_MARK("pow range check");
         cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { return proof_ext(zeta_word(i)); }, fri_alpha);
+        H2W_CLK_MARK("reduced openings 0");
         cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { return proof_ext(zeta_next_word(i)); }, fri_alpha);
+        H2W_CLK_MARK("reduced openings");
     }
     // ---- merkle strand: kind < 3: initial oracle `kind`; kind >= 3: fold step kind-3.  bits/cap_index are wires of the query.
     HF uint64_t query_word(int q) const { return pl.queries + (uint64_t)q * pl.query_words; }
     HF uint64_t initial_cap_word(int o) const {   // merkle_caps = [trace, perm_zs?, quotient] (stark/mod.rs:323-326)
-        if (o == 0) return pl.trace_cap;
-        if (s.n_perm_z > 0 && o == 1) return pl.perm_cap;
-        return pl.quotient_cap;
+        const uint64_t t = pl.trace_cap, p = pl.perm_cap, q = pl.quotient_cap;      // (read, THEN picked: loads under the conditions are merged into one load at a selected offset, and an object read at a run-time offset stays in scratch memory - chips.h SelArr)
+        return o == 0 ? t : s.n_perm_z > 0 && o == 1 ? p : q;
     }
     // proof words as an indexable view (a leaf is read once, word by word: no per-lane copy of it)
     struct ProofGl { B *be; uint64_t base; HF Gl operator[](int i) const { return be->proof_gl(base + (uint64_t)i); } };

@@ -1,0 +1,51 @@
+// Host check of csrc/glptab.h: the derived tables reproduce plonky2's fast partial rounds (hash/poseidon/permutation.rs:245-262, with
+// mds_partial_layer_init before them) when every round's row sum is kept as an accumulator - the form csrc/glperm.h runs on the device.
+// g++ -O2 -std=c++17 -I halo2-plonky2-verifier_amd/csrc -I include tests/cpp/glperm_check.cpp
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "glptab.h"
+using namespace h2w;
+
+static uint64_t pow7(uint64_t x) { const uint64_t x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x4 = gl_mul(x2, x2); return gl_mul(x3, x4); }
+
+int main() {
+    uint64_t seed = 0x9E3779B97F4A7C15ull; auto rnd = [&] { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed % GL_P; };
+    int bad = 0;
+    for (int trial = 0; trial < 50; trial++) {
+        static h2w_poseidon_consts_t k; memset(&k, 0, sizeof k);
+        for (int i = 0; i < 12; i++) { k.mds_circ[i] = trial & 1 ? rnd() : 1 + rnd() % 63; k.mds_diag[i] = i == 0 ? (trial & 1 ? rnd() : 8) : 0; }
+        for (int i = 0; i < 22; i++) k.fast_partial_round_constants[i] = trial == 7 ? GL_P - 1 : rnd();
+        for (int i = 0; i < 11; i++) for (int j = 0; j < 11; j++) k.fast_partial_round_initial_matrix[i][j] = rnd();
+        for (int i = 0; i < 22; i++) for (int j = 0; j < 11; j++) { k.fast_partial_round_w_hats[i][j] = trial == 7 ? GL_P - 1 - j : rnd(); k.fast_partial_round_vs[i][j] = rnd(); }
+        std::vector<uint64_t> aux(GLP_AUX_WORDS); glp_aux_tables(k, aux.data());
+        for (int kk = 0; kk < N_PARTIAL_ROUNDS; kk++) for (int j = 0; j < kk; j++) if (aux[XO_C + N_PARTIAL_ROUNDS * kk + j] != 0) { printf("C[%d][%d] not zero\n", kk, j); bad++; }
+        uint64_t x[12]; for (int i = 0; i < 12; i++) x[i] = trial == 9 ? GL_P - 1 - i : rnd();
+        // the reference walk
+        uint64_t s[12]; s[0] = x[0];
+        for (int c = 1; c < 12; c++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(k.fast_partial_round_initial_matrix[r - 1][c - 1], x[r], a); s[c] = a; }
+        const uint64_t m00 = (uint64_t)(k.mds_circ[0] + k.mds_diag[0]) % GL_P;      // (a wrapping u64 sum: chips.h mds_partial_layer_fast)
+        for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
+            const uint64_t a = gl_add(pow7(s[0]), k.fast_partial_round_constants[r]);
+            uint64_t d = gl_mul(m00, a);
+            for (int i = 1; i < 12; i++) d = gl_muladd(k.fast_partial_round_w_hats[r][i - 1], s[i], d);
+            for (int i = 1; i < 12; i++) s[i] = gl_muladd(k.fast_partial_round_vs[r][i - 1], a, s[i]);
+            s[0] = d;
+        }
+        // the accumulator form: "lanes" 1..11 hold s_i, "lanes" 16..37 the row sums
+        uint64_t st[12], A[N_PARTIAL_ROUNDS];
+        for (int c = 1; c < 12; c++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(k.fast_partial_round_initial_matrix[r - 1][c - 1], x[r], a); st[c] = a; }
+        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(aux[XO_G + N_PARTIAL_ROUNDS * (r - 1) + j], x[r], a); A[j] = a; }
+        uint64_t s0 = x[0];
+        for (int kk = 0; kk < N_PARTIAL_ROUNDS; kk++) {
+            const uint64_t a = gl_add(pow7(s0), k.fast_partial_round_constants[kk]);
+            for (int i = 1; i < 12; i++) st[i] = gl_muladd(k.fast_partial_round_vs[kk][i - 1], a, st[i]);
+            for (int j = 0; j < N_PARTIAL_ROUNDS; j++) A[j] = gl_muladd(aux[XO_C + N_PARTIAL_ROUNDS * kk + j], a, A[j]);
+            s0 = A[kk];
+        }
+        st[0] = s0;
+        for (int i = 0; i < 12; i++) if (st[i] != s[i]) { printf("trial %d element %d differs\n", trial, i); bad++; }
+    }
+    printf(bad ? "FAILED\n" : "OK\n");
+    return bad != 0;
+}

@@ -121,3 +121,27 @@ def test_replay_interpreter_reads_its_tape_with_scalar_loads(tmp_path):
     assert _count(lines, lo, end, "s_load_dword") >= 50, "the interpreter no longer reads its tape with scalar loads"
     assert _count(lines, lo, end, "global_load") + _count(lines, lo, end, "flat_load") <= 40, "vector loads crept into the interpreter (tape words? operands outside LDS?)"
     assert _count(lines, lo, end, "ds_read") >= 50
+
+
+def test_goldilocks_values_permutation_stays_at_its_instruction_count(tmp_path):
+    """glp_permute_lanes (glperm.h: the values phase's Goldilocks permutation, one wavefront, the floor of the prologue): a lone wavefront pays ~4.5 cycles per
+    instruction AND per wait state, so the count is the time.  The partial-round loop (two rounds per trip) is four products and two lane swaps a round;
+    the function touches memory twice (the list word on the way in, nothing else), never scratch; a row of the MDS layer reads its 24 lane values
+    without a wait state between them (the hand-scheduled block: left to the compiler there were 24)."""
+    lines = _asm("glue.hip", tmp_path)
+    lo, hi = _function(lines, "_ZN3h2w17glp_permute_lanes")
+    _clean(lines, lo, hi, "Goldilocks values permutation")
+    assert _count(lines, lo, hi, "global_store") == 1 and _count(lines, lo, hi, "global_load") == 0
+    assert not [l for l in lines[lo + 4:hi - 2] if re.search(r"s_waitcnt.*vmcnt", l)], "a vector-memory wait inside the permutation"
+    loops = list(_loops(lines, lo, hi))
+    partial = [(a, b) for a, b in loops if _count(lines, a, b, "v_permlane16_swap") == 4 and _count(lines, a, b, "v_readlane") <= 8]
+    assert partial, "partial-round loop (two rounds: four lane swaps, four v_readlane) not found"
+    a, b = min(partial, key=lambda ab: ab[1] - ab[0])
+    valu = _count(lines, a, b, "v_")
+    waits = sum(int(m.group(1)) + 1 for l in lines[a:b + 1] for m in [re.match(r"^\s+s_nop\s+(\d+)", l)] if m)
+    assert valu <= 200 and valu + waits <= 240, f"two partial rounds grew to {valu} vector instructions and {waits} wait states"
+    mds = [i for i in range(lo, hi) if re.match(r"^\s+v_readlane_b32 s20, v\d+, 0", lines[i])]
+    assert len(mds) >= 2, "the hand-scheduled MDS rows (first and second half) are gone"
+    for i in mds:
+        blk = lines[i:i + 52]
+        assert sum(1 for l in blk if re.match(r"^\s+v_readlane", l)) == 24 and sum(1 for l in blk[:50] if re.match(r"^\s+s_nop", l)) == 0

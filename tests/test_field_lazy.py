@@ -46,3 +46,15 @@ def test_fri_constants_table_equals_the_per_call_formulas(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "fri_tab_check.cpp"), "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_partial_round_accumulator_tables_reproduce_the_fast_partial_rounds(tmp_path):
+    """csrc/glptab.h (what h2w_plan_compile uploads behind the Poseidon constants for the values phase, csrc/glperm.h): the partial rounds with one
+    accumulator per round instead of one row sum per round give the state the reference walk gives, on tiny-entry and full-width tables."""
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = os.path.join(str(tmp_path), "glperm_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "halo2-plonky2-verifier_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "glperm_check.cpp"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -76,6 +76,27 @@ def test_values_pass_forms_on_the_published_tables_and_on_valid_proofs(h2w, h2w_
     run_batch(h2w, h2w_api, oracle, consts, (7, 5, 2, 1), [71, 72, 73, 74, 75, 76, 77], passes=2, values_form=form)      # 35 units: partly filled blocks of four wavefronts
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("table", ["full_width", "largest_small", "just_beyond_small"])
+def test_goldilocks_mds_tables_of_every_width(h2w, h2w_api, oracle, consts, mode, table):
+    """The values phase walks a small-entry Goldilocks MDS matrix as two 64-bit sums and one reduction (csrc/glperm.h glq_mds_small: entries below 2^26,
+    coop.h glp_small_mds) and any other with one multiply-add per entry: both paths, and the bound between them, against the oracle - the synthetic and
+    the published tables are all tiny-entry ones.  Challenger permutations in both hash modes, Merkle permutations too with Goldilocks caps."""
+    ko0, _ = consts
+    ko = oracle.Consts.from_buffer_copy(bytes(ko0))
+    p = 2**64 - 2**32 + 1
+    for i in range(12):
+        if table == "full_width":
+            ko.mds_circ[i] = (0x9E3779B97F4A7C15 * (i + 1)) % p; ko.mds_diag[i] = (0xD1B54A32D192ED03 * (i + 3)) % p
+        else:
+            ko.mds_circ[i] = 2**26 - 1 - (i % 3); ko.mds_diag[i] = 2**26 - 1 if i in (0, 5) else 0
+    if table == "just_beyond_small":
+        ko.mds_circ[7] = 2**26
+    kh = h2w.PoseidonConsts.from_buffer_copy(bytes(ko))
+    run_batch(h2w, h2w_api, oracle, (ko, kh), (7, 3, 2, mode), [91, 92])          # one fold step
+    run_batch(h2w, h2w_api, oracle, (ko, kh), (6, 2, 1, mode), [93], valid=True, cap_height=2)
+
+
 @pytest.mark.parametrize("lookup_bits", [13, 8, 17])
 def test_other_lookup_bits(h2w, h2w_api, oracle, consts, lookup_bits):
     run_batch(h2w, h2w_api, oracle, consts, (7, 2, 1, 1), [7], lookup_bits=lookup_bits)

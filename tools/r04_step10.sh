@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-bash tools/r04_step9.sh -DH2W_GLP_V1
+bash tools/r04_step9.sh
 timeout -k 10 200 python3 tools/launch_timing.py --batch 1 --reps 3 > gpurun_out/r04_one_proof_after.txt 2>&1
 timeout -k 10 200 python3 tools/launch_timing.py --batch 1 --reps 3 --hash gl >> gpurun_out/r04_one_proof_after.txt 2>&1
 cat gpurun_out/r04_one_proof_after.txt

@@ -1,5 +1,6 @@
 // Micro-benchmark + check of the values-phase Goldilocks Poseidon permutation (csrc/glperm.h) on ONE wavefront: a chain of n permutations against a
-// plain host walk of the same fast form over the same (random, canonical) constants, and the cycles one permutation takes.
+// plain host walk of the same fast form over the same (random, canonical) constants, and the cycles one permutation takes (the round-3 form, in the
+// history before this file: 31.0 k cycles on the small-entry path, 41.8 k on the dense one: profiles/r04_ubench_glperm.txt).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I halo2-plonky2-verifier_amd/csrc -I include tools/ubench/ubench_glperm.hip -o gpurun_out/ubench_glperm
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -17,10 +18,6 @@ template <int V> __global__ void k_perm(const h2w_poseidon_consts_t *k, uint64_t
     uint64_t x = lane < SPONGE_WIDTH ? io[lane] : 0;
     const long long t0 = clock64();
     for (int i = 0; i < n; i++) {
-#ifdef H2W_GLP_V1
-        if (V == 0) x = glp_permute_lanes_v1(x, (lds64_t *)s_glp_k, (lds64_t *)s_glp_m, lane, small != 0);
-        else
-#endif
         x = glp_permute_lanes(x, (lds64_t *)s_glp_k, (lds64_t *)s_glp_m, (lds64_t *)s_glp_x, lane, small != 0);
     }
     const long long t1 = clock64();
@@ -43,7 +40,7 @@ static void host_perm(uint64_t *s, const uint64_t *K) {      // hash/poseidon/pe
     { uint64_t o[12]; o[0] = s[0]; for (int c = 1; c < 12; c++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = hadd(a, hmul(K[KO_INIT + (r - 1) * 11 + (c - 1)], s[r])); o[c] = a; } memcpy(s, o, sizeof o); }
     for (int r = 0; r < 22; r++) {
         const uint64_t s0 = hadd(hpow7(s[0]), K[KO_PRC + r]);
-        uint64_t d = hmul(hadd(K[KO_CIRC], K[KO_DIAG]), s0);
+        uint64_t d = hmul((uint64_t)(K[KO_CIRC] + K[KO_DIAG]) % GL_P, s0);      // (a wrapping u64 sum, as the reference forms it)
         for (int i = 1; i < 12; i++) d = hadd(d, hmul(K[KO_WHAT + r * 11 + i - 1], s[i]));
         for (int i = 1; i < 12; i++) s[i] = hadd(s[i], hmul(K[KO_VS + r * 11 + i - 1], s0));
         s[0] = d;
@@ -56,23 +53,20 @@ int main() {
     h2w_poseidon_consts_t *dk; uint64_t *io; long long *cyc;
     CK(hipMalloc(&dk, sizeof(h2w_poseidon_consts_t) + GLP_AUX_WORDS * 8)); CK(hipMalloc(&io, 24 * 8)); CK(hipMalloc(&cyc, 8));
     int bad_total = 0;
-    for (int cfg = 0; cfg < 4; cfg++) {      // 0: tiny MDS entries (plonky2's are <= 41) | 1: entries up to 2^26 - 1 (the small path's bound, coop.h glp_small_mds) | 2: 64-bit entries (the dense path) | 3: extreme words
+    for (int cfg = 0; cfg < 12; cfg++) {      // 4..11: full-width entries on the diagonal too | 0: tiny MDS entries (plonky2's are <= 41) | 1: entries up to 2^26 - 1 (the small path's bound, coop.h glp_small_mds) | 2: 64-bit entries (the dense path) | 3: extreme words
         std::vector<uint64_t> K(sizeof(h2w_poseidon_consts_t) / 8, 0);
         for (int i = 0; i < GLP_CONST_WORDS; i++) K[i] = cfg == 3 ? (i % 3 == 0 ? GL_P - 1 : i % 3 == 1 ? GL_P - 1 - (rnd() & 0xFFFF) : rnd() % GL_P) : rnd() % GL_P;
         for (int i = 0; i < 12; i++) {
-            const uint64_t m = cfg == 0 ? 63 : cfg == 2 ? ~0ull : (1ull << 26) - 1;
-            K[KO_CIRC + i] = cfg == 1 || cfg == 3 ? m - (rnd() & 3) : (rnd() & m) % GL_P; K[KO_DIAG + i] = i == 0 ? (cfg == 0 ? 8 : (rnd() & m) % GL_P) : 0;
+            const uint64_t m = cfg == 0 ? 63 : cfg == 2 || cfg >= 4 ? ~0ull : (1ull << 26) - 1;
+            K[KO_CIRC + i] = cfg == 1 || cfg == 3 ? m - (rnd() & 3) : (rnd() & m) % GL_P; K[KO_DIAG + i] = i == 0 ? (cfg == 0 ? 8 : (rnd() & m) % GL_P) : cfg >= 4 ? (rnd() & m) % GL_P : 0;
         }
         if (cfg == 1 || cfg == 3) K[KO_CIRC] = (1ull << 26) - 1;
-        const int small = cfg != 2;
+        const int small = cfg != 2 && cfg < 4;
         CK(hipMemcpy(dk, K.data(), sizeof(h2w_poseidon_consts_t), hipMemcpyHostToDevice));
         { std::vector<uint64_t> aux(GLP_AUX_WORDS); glp_aux_tables(*reinterpret_cast<const h2w_poseidon_consts_t *>(K.data()), aux.data()); CK(hipMemcpy(dk + 1, aux.data(), GLP_AUX_WORDS * 8, hipMemcpyHostToDevice)); }
         uint64_t st[12]; for (int i = 0; i < 12; i++) st[i] = cfg == 3 ? GL_P - 1 - i : rnd() % GL_P;
         const int n = 64;
-        for (int V = 0; V < 2; V++) {
-#ifndef H2W_GLP_V1
-            if (V == 0) continue;
-#endif
+        for (int V = 1; V < 2; V++) {
             CK(hipMemcpy(io, st, 12 * 8, hipMemcpyHostToDevice));
             for (int rep = 0; rep < 2; rep++) {
                 CK(hipMemcpy(io, st, 12 * 8, hipMemcpyHostToDevice));
@@ -84,7 +78,7 @@ int main() {
             uint64_t ref[12]; memcpy(ref, st, sizeof ref); for (int i = 0; i < n; i++) host_perm(ref, K.data());
             int bad = 0; for (int i = 0; i < 12; i++) bad += out[i] != ref[i];
             bad_total += bad;
-            printf("constants %d (%s), %s form: %.0f cycles per permutation, mismatching elements %d of 12\n", cfg, small ? "small MDS path" : "dense MDS path", V ? "round-4" : "round-3", (double)c / n, bad);
+            printf("constants %d (%s), %s form: %.0f cycles per permutation, mismatching elements %d of 12\n", cfg, small ? "small MDS path" : "dense MDS path", "round-4", (double)c / n, bad);
         }
     }
     printf(bad_total ? "FAILED\n" : "OK\n");
