@@ -13,9 +13,10 @@
 
 namespace h2w {
 
-// One scheduling fence: the hazard recogniser does not look inside an asm block, so an asm result that the NEXT instruction reads through DPP, a lane
-// swap or v_readlane needs its wait states spelled out (gfx940 family: 2 for DPP / swaps, 1 for v_readlane).
-__device__ __forceinline__ void glq_lane_fence(uint64_t &v) { asm volatile("s_nop 1" : "+v"(v)); }      // (tied to the value: stays between its producer and its readers)
+// One scheduling fence: the hazard recogniser does not look inside an asm block, so an asm result that the NEXT instruction reads through v_readlane or
+// DPP needs its wait states spelled out (gfx940 family: 1 for v_readlane, 2 for DPP).  A lane swap (v_permlane16/32_swap of a value with itself) needs
+// none: its operands are tied, one of them is always a fresh copy of the value, and the compiler itself puts the swap's two wait states behind that copy.
+template <int N = 1> __device__ __forceinline__ void glq_lane_fence(uint64_t &v) { asm volatile("s_nop %1" : "+v"(v) : "n"(N)); }      // (tied to the value: stays between its producer and its readers)
 
 // lo + p2 2^64 + p3 2^96 (mod p), 2^64 = 2^32 - 1 = eps, 2^96 = -1:  u = lo + p2 eps (carry c), v = u - p3 (borrow b), r = v + (c - b) eps.
 // r does not wrap: c and not b: v + 2^64 is the true sum <= 2^65 - 2^33, so v + eps < 2^64;  b and not c: v - 2^64 > -2^32, so v - eps > 0.
@@ -143,7 +144,7 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
     // x^7: x^2, then x^3 on the even rows and x^4 on the odd ones in one product, then their product on every row
     auto sbox = [&](uint64_t v) {
         const uint64_t v2 = glq_mul(v, v); uint64_t t = glq_mul(v2, odd_row ? v2 : v);
-        uint64_t e, o; glq_lane_fence(t); glq_pair_rows(t, e, o);
+        uint64_t e, o; glq_pair_rows(t, e, o);
         return glq_mul(e, o);
     };
     // S-box layer and MDS layer of one full round, and the constant layer of what follows it (next: canonical) in the same sums
@@ -152,7 +153,7 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
         if (small) x = glq_mds_small(x, mrow, next);
         else {
             uint64_t acc = next;
-            glq_lane_fence(x);
+            glq_lane_fence<0>(x);
 #pragma unroll
             for (int j = 0; j < SPONGE_WIDTH; j++) acc = glq_muladd(M[lc * SPONGE_WIDTH + j], readlane64(x, j), acc);
             x = acc;
@@ -169,33 +170,33 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
     // ---- the partial rounds, their row sums unrolled.  Round k turns s0 into a_k = s0^7 + c_k, then s0 <- m00 a_k + sum_i w_hat[k][i] s_i and
     // s_i <- s_i + v[k][i] a_k: every s_i is its value at the start plus a combination of the a's so far, and so is every row sum.  Lane 16 + j keeps
     // A_j = (row sum of round j over the start values) + sum_{k < j} C[k][j] a_k, with C[j][j] = m00 its last term: after round j it IS the next s0.
-    // So a round is the S-box of ONE value - computed by every lane, x^3 on the even rows and x^4 on the odd ones - and ONE multiply-add on every
+    // So a round is the S-box of ONE value - computed by every lane, x^3 on the even rows and x^4 on the odd ones; the c_k are in the sums from the start
+    // (glptab.h Q) - and ONE multiply-add on every
     // lane (lanes 1..11: s_i += v[k][i] a_k, lanes 16..37: A_j += C[k][j] a_k); no row sum, no sparse-row products.  The start values and the row sums
     // over them come out of the same eleven multiply-adds (mds_partial_layer_init on lanes 1..11, its products with the w_hat rows, G, on lanes 16..37).
     const bool st_lane = l >= 1 && l < SPONGE_WIDTH, acc_lane = l >= 16 && l < 16 + N_PARTIAL_ROUNDS;
     lds64_t *t_init = st_lane ? K + KO_INIT + (l - 1) : acc_lane ? X + XO_G + (l - 16) : X + XO_C + N_PARTIAL_ROUNDS;      // (C[1][0] = 0: the lanes with no part in it)
     lds64_t *t_round = st_lane ? K + KO_VS + (l - 1) : acc_lane ? X + XO_C + (l - 16) : X + XO_C + N_PARTIAL_ROUNDS;
     const int t_step = st_lane ? 11 : acc_lane ? N_PARTIAL_ROUNDS : 0;
-    uint64_t acc = 0;
-    glq_lane_fence(x);
+    uint64_t acc = X[XO_Q + l];      // (the round constants' share of this lane's sum: the rounds below add multiples of s0^7 alone)
+    glq_lane_fence<0>(x);
     uint64_t s0 = readlane64(x, 0);
 #pragma unroll
     for (int r = 1; r < SPONGE_WIDTH; r++) acc = glq_muladd(t_init[(r - 1) * t_step], readlane64(x, r), acc);
-    uint64_t tk_n = t_round[0], prc_n = K[KO_PRC];
+    uint64_t tk_n = t_round[0];
 #pragma unroll 2
     for (int k = 0; k < N_PARTIAL_ROUNDS; k++) {
-        const uint64_t tk = tk_n, prc = prc_n;
-        { const int kn = k + 1 < N_PARTIAL_ROUNDS ? k + 1 : k; tk_n = t_round[kn * t_step]; prc_n = K[KO_PRC + kn]; }
+        const uint64_t tk = tk_n;
+        { const int kn = k + 1 < N_PARTIAL_ROUNDS ? k + 1 : k; tk_n = t_round[kn * t_step]; }
         asm("" : "+v"(s0));      // (a lane's copy, not a scalar: on the scalar unit a 64 x 64 product is ~35 instructions)
         const uint64_t s2 = glq_mul(s0, s0); uint64_t t = glq_mul(s2, odd_row ? s2 : s0);
-        uint64_t e, o; glq_lane_fence(t); glq_pair_rows(t, e, o);
-        const uint64_t a = glq_muladd(e, o, prc);
+        uint64_t e, o; glq_pair_rows(t, e, o);
+        const uint64_t a = glq_mul(e, o);
         acc = glq_muladd(tk, a, acc);
-        glq_lane_fence(acc);
+        glq_lane_fence<0>(acc);
         s0 = readlane64(acc, 16 + k);
     }
     x = l == 0 ? s0 : acc;
-    glq_lane_fence(x);
     x = glq_bcast_row0(x);
     x = glq_add(x, K[KO_ARC + SPONGE_WIDTH * (HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS) + lc]);
     arc_n = K[KO_ARC + SPONGE_WIDTH * (HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS + 1) + lc];

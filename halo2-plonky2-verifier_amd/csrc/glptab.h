@@ -12,7 +12,9 @@ namespace h2w {
 // (glp_aux_tables) and kept behind the constants on the device:
 //   C[k][j] (XO_C + 22 k + j): what round k's S-box output a_k adds to s0 of round j + 1:  sum_i w_hat[j][i] v[k][i] for k < j, circ0 + diag0 for k = j, 0 for k > j
 //   G[r][j] (XO_G + 22 (r - 1) + j): what element r (1..11) of the state BEFORE mds_partial_layer_init adds to round j's row sum:  sum_c w_hat[j][c] init[r-1][c-1]
-constexpr int XO_C = 0, XO_G = N_PARTIAL_ROUNDS * N_PARTIAL_ROUNDS, GLP_AUX_WORDS = XO_G + 11 * N_PARTIAL_ROUNDS;
+//   Q[l] (XO_Q + l, l = lane 0..63): what the round constants c_k add to lane l's value over all 22 rounds - sum_k v[k][i] c_k on lane i = 1..11, sum_k C[k][j] c_k on
+//            lane 16 + j - so that the rounds multiply by s0^7 alone and the constants are in the sums from the start
+constexpr int XO_C = 0, XO_G = N_PARTIAL_ROUNDS * N_PARTIAL_ROUNDS, XO_Q = XO_G + 11 * N_PARTIAL_ROUNDS, GLP_AUX_WORDS = XO_Q + 64;
 inline void glp_aux_tables(const h2w_poseidon_consts_t &c, uint64_t *aux) {
     for (int k = 0; k < N_PARTIAL_ROUNDS; k++)
         for (int j = 0; j < N_PARTIAL_ROUNDS; j++) {
@@ -27,6 +29,14 @@ inline void glp_aux_tables(const h2w_poseidon_consts_t &c, uint64_t *aux) {
             for (int i = 0; i < 11; i++) a = gl_muladd(c.fast_partial_round_w_hats[j][i] % GL_P, c.fast_partial_round_initial_matrix[r][i] % GL_P, a);
             aux[XO_G + N_PARTIAL_ROUNDS * r + j] = a;
         }
+    for (int l = 0; l < 64; l++) {
+        uint64_t a = 0;
+        for (int k = 0; k < N_PARTIAL_ROUNDS; k++) {
+            const uint64_t t = l >= 1 && l < SPONGE_WIDTH ? c.fast_partial_round_vs[k][l - 1] % GL_P : l >= 16 && l < 16 + N_PARTIAL_ROUNDS ? aux[XO_C + N_PARTIAL_ROUNDS * k + (l - 16)] : 0;
+            a = gl_muladd(t, c.fast_partial_round_constants[k] % GL_P, a);
+        }
+        aux[XO_Q + l] = a;
+    }
 }
 
 }      // namespace h2w

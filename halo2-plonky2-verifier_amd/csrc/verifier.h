@@ -172,7 +172,13 @@ template <class B> struct Verifier {
         for (int i = 0; i < s.num_queries; i++) cb.fri_query_indices[i] = ch.get_challenge();
         H2W_CLK_MARK("query indices");
         // verify_proof_with_challenges: fri_instance_info (stark/mod.rs:144-200): zeta_next = g * zeta
-        { gle_t gv; gv.c[0] = gl_primitive_root_of_unity(s.degree_bits); gv.c[1] = 0; Ex g = ext.load_constant(gv); cb.zeta_next = ext.mul(g, zeta); }
+        {   // (the generator of the trace domain is the LDE domain's, squared rate_bits times: with the shape's table at hand that replaces an exponentiation - 33 k cycles of the prologue wavefront)
+            const FriTab *ft = be.fri_tab();
+            uint64_t gd;
+            if (ft && ft->lde_bits == s.degree_bits + s.rate_bits) { gd = ft->root_lde; for (int i = 0; i < s.rate_bits; i++) gd = gl_mul(gd, gd); }
+            else gd = gl_primitive_root_of_unity(s.degree_bits);
+            gle_t gv; gv.c[0] = gd; gv.c[1] = 0; Ex g = ext.load_constant(gv); cb.zeta_next = ext.mul(g, zeta);
+        }
         H2W_CLK_MARK("zeta_next");
         // FriChip::verify_fri_proof (fri/mod.rs:446-502): PoW (:130-145), from_os_and_alpha (:45-62)
         be.range_check(pow_response, 64 - s.pow_bits);

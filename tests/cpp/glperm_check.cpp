@@ -19,6 +19,7 @@ int main() {
         for (int i = 0; i < 11; i++) for (int j = 0; j < 11; j++) k.fast_partial_round_initial_matrix[i][j] = rnd();
         for (int i = 0; i < 22; i++) for (int j = 0; j < 11; j++) { k.fast_partial_round_w_hats[i][j] = trial == 7 ? GL_P - 1 - j : rnd(); k.fast_partial_round_vs[i][j] = rnd(); }
         std::vector<uint64_t> aux(GLP_AUX_WORDS); glp_aux_tables(k, aux.data());
+        for (int l = 0; l < 64; l++) if (!(l >= 1 && l < 12) && !(l >= 16 && l < 38) && aux[XO_Q + l] != 0) { printf("Q[%d] not zero\n", l); bad++; }
         for (int kk = 0; kk < N_PARTIAL_ROUNDS; kk++) for (int j = 0; j < kk; j++) if (aux[XO_C + N_PARTIAL_ROUNDS * kk + j] != 0) { printf("C[%d][%d] not zero\n", kk, j); bad++; }
         uint64_t x[12]; for (int i = 0; i < 12; i++) x[i] = trial == 9 ? GL_P - 1 - i : rnd();
         // the reference walk
@@ -35,10 +36,11 @@ int main() {
         // the accumulator form: "lanes" 1..11 hold s_i, "lanes" 16..37 the row sums
         uint64_t st[12], A[N_PARTIAL_ROUNDS];
         for (int c = 1; c < 12; c++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(k.fast_partial_round_initial_matrix[r - 1][c - 1], x[r], a); st[c] = a; }
-        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(aux[XO_G + N_PARTIAL_ROUNDS * (r - 1) + j], x[r], a); A[j] = a; }
+        for (int c = 1; c < 12; c++) st[c] = gl_add(st[c], aux[XO_Q + c]);      // the round constants' share, from the start (lanes 1..11 and 16..37)
+        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) { uint64_t a = aux[XO_Q + 16 + j]; for (int r = 1; r < 12; r++) a = gl_muladd(aux[XO_G + N_PARTIAL_ROUNDS * (r - 1) + j], x[r], a); A[j] = a; }
         uint64_t s0 = x[0];
         for (int kk = 0; kk < N_PARTIAL_ROUNDS; kk++) {
-            const uint64_t a = gl_add(pow7(s0), k.fast_partial_round_constants[kk]);
+            const uint64_t a = pow7(s0);      // (no constant: it is in the sums)
             for (int i = 1; i < 12; i++) st[i] = gl_muladd(k.fast_partial_round_vs[kk][i - 1], a, st[i]);
             for (int j = 0; j < N_PARTIAL_ROUNDS; j++) A[j] = gl_muladd(aux[XO_C + N_PARTIAL_ROUNDS * kk + j], a, A[j]);
             s0 = A[kk];

@@ -1,0 +1,8 @@
+#!/bin/bash
+# round-4: the permutation alone and in the prologue (quick check between edits)
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+bash tools/r04_step9.sh | grep -v "constants [4-9]\|constants 1[01]"
+timeout -k 10 200 python3 tools/launch_timing.py --batch 1 --reps 3 2>/dev/null | grep config
+timeout -k 10 300 python -m pytest tests/test_gpu_batch.py -x -q -m gpu -k "small_shapes or mds_tables or published or valid_fri" 2>&1 | tail -2
