@@ -528,15 +528,17 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     bool forked = false;
     auto body = [&]() -> int {
         H2W_HIP(hipEventRecord(ev[0], stream));
-        // 0. witness load + cap-hash limb decompositions: one lane per (proof, item)
+        // 1. prologue strands, values: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks.  FIRST: everything
+        //    else of the launch waits for the challenges, nothing for the load cells
+        launch_prologue_values(A, stream);
+        H2W_HIP(hipEventRecord(ev[9], stream));
+        // 0. witness load + cap-hash limb decompositions: one lane per (proof, item).  Cells and a flag word only (nobody's input): behind the prologue, beside the
+        //    Merkle chains that fork off at this point
         H2W_HIP(hipMemsetAsync(A.load_flag, 0, n_proofs * sizeof(uint32_t), stream));
         if (p->n_items + p->n_cap_items) {
             const dim3 lgrid((p->n_items + p->n_cap_items + 255) / 256, (unsigned)n_proofs);
             if (cm.starts) hipLaunchKernelGGL(k_prologue_load<true>, lgrid, dim3(256), 0, stream, A); else hipLaunchKernelGGL(k_prologue_load<false>, lgrid, dim3(256), 0, stream, A);
         }
-        // 1. prologue strands, values: one wavefront per proof (witness load, Fiat-Shamir sponge, PoW, reduced openings) -> challenge blocks
-        launch_prologue_values(A, stream);
-        H2W_HIP(hipEventRecord(ev[9], stream));
         // 2. the records of the listed Goldilocks-Poseidon permutations: with PoseidonBN254 caps the prologues' (now); with Goldilocks caps
         //    together with the Merkle strands' (below)
         const unsigned n_pro_perms = A.sh.n_own_proofs * p->st.pro_nglp, n_mk_perms = nunits * p->st.q_nglp;

@@ -131,6 +131,12 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         for (int base = 0; base < n; base += 64) { const int i = base + lane; if (i < n) lin[sp_in + i] = g_load_u64(proof + word(i)); }
         sp_in += n; return true;
     }
+    // proof words staged side by side in the (idle) input buffer, one lane a word: what the strand then reads one by one costs an LDS read each instead
+    // of a dependent global load (~2.4 k cycles for a wavefront with nothing else to run)
+    template <class WordFn> __device__ __forceinline__ void stage_words(const uint64_t *proof, int at, int n, WordFn word) {
+        for (int base = 0; base < n; base += 64) { const int i = base + lane; if (i < n) lin[at + i] = g_load_u64(proof + word(i)); }
+    }
+    __device__ __forceinline__ uint64_t staged_word(int i) const { return lin[i]; }
     // observe_cap (challenger/mod.rs:65-74): hash j of the cap on lane j; Goldilocks hashes are their 4 words, BN254 hashes 5 limbs of 56 bits
     // (HashWire::to_goldilocks_vec, hash/poseidon_bn254/hash.rs:31-43: decompose_le(56, 5) - its cells are k_prologue_load's)
     __device__ __forceinline__ bool sponge_observe_cap(const uint64_t *proof, uint64_t w0, int n, int mode, int L) {      // (inlined, like sponge_challenge: an out-of-line member takes the sink's address, and a sink in memory pays a scratch round trip behind the record stores for every counter it bumps)
@@ -179,7 +185,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         if (sp_in) {
             for (int off = 0; off < sp_in; off += SPONGE_RATE) {
                 const int len = sp_in - off < SPONGE_RATE ? sp_in - off : SPONGE_RATE;
-                if (lane < len) sx = lin[off + lane];
+                if ((lane & 15) < len) sx = lin[off + (lane & 15)];      // (every 16-lane row alike: glperm.h)
                 sponge_permute();
             }
             sp_in = 0; sp_out = SPONGE_RATE;
@@ -192,7 +198,7 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
             // values phase: list the permutation (lane 0: where its records start; lanes 1..12: the input state), compute its output
             uint64_t w = nrec, x = 0;
 #pragma unroll
-            for (int i = 0; i < SPONGE_WIDTH; i++) { if (lane == i + 1) w = st[i]; if (lane == i) x = st[i]; }
+            for (int i = 0; i < SPONGE_WIDTH; i++) { if (lane == i + 1) w = st[i]; if ((lane & 15) == i) x = st[i]; }      // (every 16-lane row alike: glperm.h)
             uint64_t *at = emit && lane < GLP_LIST_WORDS ? glp + (uint64_t)glp_slot * GLP_LIST_WORDS + lane : nullptr;
             glp_slot++;
             x = glp_permute_lanes(x, lk, lm, lx, lane, small_mds, at, w);

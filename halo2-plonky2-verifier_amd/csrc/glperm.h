@@ -121,8 +121,28 @@ __device__ __forceinline__ uint64_t glq_mds_small(uint64_t x, const uint32_t (&m
     return r;
 }
 
-// Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES.  Lane l < 12 holds state element l and returns its element
-// of the output; the other three rows of the wavefront repeat row 0 (their lanes 12..15, like row 0's, compute along on element 11 and are ignored).
+// Twelve terms of the linear layer between the fourth S-box layer and the partial rounds (glptab.h W): a0 += lo32(w_i) y_i, a1 += hi32(w_i) y_i, where y_i is
+// lane i's 22-bit limb (v_readlane; three scalar registers in rotation: a v_readlane result is read three instructions later) and w_i this lane's
+// entries.  36 such terms stay below 2^59.2: no reduction between them.
+__device__ __forceinline__ void glq_dense12(uint32_t limb, const uint32_t (&wl)[SPONGE_WIDTH], const uint32_t (&wh)[SPONGE_WIDTH], uint64_t &a0, uint64_t &a1) {
+#define H2W_D12(i, sr) "v_mad_u64_u32 %[a0], vcc, " sr ", %[l" #i "], %[a0]\n\t" "v_mad_u64_u32 %[a1], vcc, " sr ", %[h" #i "], %[a1]\n\t"
+#define H2W_D12R(i, sr, n) H2W_D12(i, sr) "v_readlane_b32 " sr ", %[y], " #n "\n\t"
+    asm("s_nop 0\n\t"
+        "v_readlane_b32 s20, %[y], 0\n\t" "v_readlane_b32 s21, %[y], 1\n\t" "v_readlane_b32 s22, %[y], 2\n\t"
+        H2W_D12R(0, "s20", 3) H2W_D12R(1, "s21", 4) H2W_D12R(2, "s22", 5) H2W_D12R(3, "s20", 6) H2W_D12R(4, "s21", 7) H2W_D12R(5, "s22", 8)
+        H2W_D12R(6, "s20", 9) H2W_D12R(7, "s21", 10) H2W_D12R(8, "s22", 11) H2W_D12(9, "s20") H2W_D12(10, "s21") H2W_D12(11, "s22")
+        : [a0] "+v"(a0), [a1] "+v"(a1)
+        : [y] "v"(limb), [l0] "v"(wl[0]), [l1] "v"(wl[1]), [l2] "v"(wl[2]), [l3] "v"(wl[3]), [l4] "v"(wl[4]), [l5] "v"(wl[5]), [l6] "v"(wl[6]), [l7] "v"(wl[7]), [l8] "v"(wl[8]),
+          [l9] "v"(wl[9]), [l10] "v"(wl[10]), [l11] "v"(wl[11]), [h0] "v"(wh[0]), [h1] "v"(wh[1]), [h2] "v"(wh[2]), [h3] "v"(wh[3]), [h4] "v"(wh[4]), [h5] "v"(wh[5]), [h6] "v"(wh[6]),
+          [h7] "v"(wh[7]), [h8] "v"(wh[8]), [h9] "v"(wh[9]), [h10] "v"(wh[10]), [h11] "v"(wh[11])
+        : "vcc", "s20", "s21", "s22");
+#undef H2W_D12R
+#undef H2W_D12
+}
+
+// Goldilocks Poseidon (plonky2's fast form, hash/poseidon/permutation.rs:216-284) on VALUES.  Lane l of EVERY 16-lane row holds state element l & 15
+// (l & 15 < 12; the callers keep the four rows alike: coop.h sponge_challenge, coop_poseidon_permute) and returns its element of the output on every row
+// (lanes 12..15 of a row compute along on element 11 and are ignored).
 // K: the constant block in LDS, M: the dense MDS rows, X: the derived tables of the partial rounds (stage_glp_consts<true>).
 // list_at / list_word: a word this lane leaves in memory on the way in (the strand's permutation list, coop.h sponge_permute; null: none) - issued here, it
 // has the whole permutation to complete in; issued by the caller, the entry of this function would wait for it.
@@ -133,7 +153,6 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
 #endif
     const int l15 = l & 15, lc = l15 < SPONGE_WIDTH ? l15 : SPONGE_WIDTH - 1;
     const bool odd_row = (l >> 4) & 1;
-    x = glq_bcast_row0(x);
     // this lane's row of the dense MDS matrix sits in registers for all eight full rounds (small entries: one dword each); every round's table words
     // are read a round ahead (an LDS read is ~110 cycles for a wavefront with nothing else to run)
     uint32_t mrow[SPONGE_WIDTH];
@@ -162,27 +181,42 @@ __device__ __noinline__ uint64_t glp_permute_lanes(uint64_t x, lds64_t *K, lds64
     uint64_t arc_n = K[KO_ARC + SPONGE_WIDTH + lc];
     x = glq_add(x, K[KO_ARC + lc]);
 #pragma unroll 1
-    for (int i = 0; i < HALF_N_FULL_ROUNDS; i++) {
+    for (int i = 0; i < HALF_N_FULL_ROUNDS - 1; i++) {
         const uint64_t next = arc_n;
-        arc_n = i + 2 < HALF_N_FULL_ROUNDS ? K[KO_ARC + SPONGE_WIDTH * (i + 2) + lc] : K[KO_FIRST + lc];      // (the last full round carries partial_first_constant_layer)
+        arc_n = K[KO_ARC + SPONGE_WIDTH * (i + 2 < HALF_N_FULL_ROUNDS ? i + 2 : i + 1) + lc];
         full_round(next);
     }
+    x = sbox(x);      // the fourth full round's S-box layer; its MDS layer is part of what follows
     // ---- the partial rounds, their row sums unrolled.  Round k turns s0 into a_k = s0^7 + c_k, then s0 <- m00 a_k + sum_i w_hat[k][i] s_i and
     // s_i <- s_i + v[k][i] a_k: every s_i is its value at the start plus a combination of the a's so far, and so is every row sum.  Lane 16 + j keeps
     // A_j = (row sum of round j over the start values) + sum_{k < j} C[k][j] a_k, with C[j][j] = m00 its last term: after round j it IS the next s0.
     // So a round is the S-box of ONE value - computed by every lane, x^3 on the even rows and x^4 on the odd ones; the c_k are in the sums from the start
     // (glptab.h Q) - and ONE multiply-add on every
     // lane (lanes 1..11: s_i += v[k][i] a_k, lanes 16..37: A_j += C[k][j] a_k); no row sum, no sparse-row products.  The start values and the row sums
-    // over them come out of the same eleven multiply-adds (mds_partial_layer_init on lanes 1..11, its products with the w_hat rows, G, on lanes 16..37).
+    // over them come out of ONE linear layer on the fourth S-box layer's outputs (glptab.h W).
     const bool st_lane = l >= 1 && l < SPONGE_WIDTH, acc_lane = l >= 16 && l < 16 + N_PARTIAL_ROUNDS;
-    lds64_t *t_init = st_lane ? K + KO_INIT + (l - 1) : acc_lane ? X + XO_G + (l - 16) : X + XO_C + N_PARTIAL_ROUNDS;      // (C[1][0] = 0: the lanes with no part in it)
-    lds64_t *t_round = st_lane ? K + KO_VS + (l - 1) : acc_lane ? X + XO_C + (l - 16) : X + XO_C + N_PARTIAL_ROUNDS;
+    lds64_t *t_round = st_lane ? K + KO_VS + (l - 1) : acc_lane ? X + XO_C + (l - 16) : X + XO_C + N_PARTIAL_ROUNDS;      // (C[1][0] = 0: the lanes with no part in it)
     const int t_step = st_lane ? 11 : acc_lane ? N_PARTIAL_ROUNDS : 0;
-    uint64_t acc = X[XO_Q + l];      // (the round constants' share of this lane's sum: the rounds below add multiples of s0^7 alone)
-    glq_lane_fence<0>(x);
-    uint64_t s0 = readlane64(x, 0);
+    // the linear layer onto the lanes of the partial rounds (glptab.h W: MDS layer, first constants, initial matrix, every round's row sum over the start
+    // values and the round constants' share, composed): 36 = 12 x 3 limbs of 22 bits, two sums, one reduction
+    uint64_t acc;
+    {
+        const int slot = glp_slot_of_lane(l);
+        lds64_t *wp = X + XO_W + slot;
+        const uint64_t w0 = X[XO_W0 + slot];
+        uint64_t a0 = (uint32_t)w0, a1 = w0 >> 32;
+        const uint32_t y0 = (uint32_t)x & 0x3FFFFF, y1 = (uint32_t)(x >> 22) & 0x3FFFFF, y2 = (uint32_t)(x >> 44);
 #pragma unroll
-    for (int r = 1; r < SPONGE_WIDTH; r++) acc = glq_muladd(t_init[(r - 1) * t_step], readlane64(x, r), acc);
+        for (int t = 0; t < 3; t++) {
+            uint32_t wl[SPONGE_WIDTH], wh[SPONGE_WIDTH];
+#pragma unroll
+            for (int i = 0; i < SPONGE_WIDTH; i++) { const uint64_t w = wp[(SPONGE_WIDTH * t + i) * GLP_SLOTS]; wl[i] = (uint32_t)w; wh[i] = (uint32_t)(w >> 32); }
+            glq_dense12(t == 0 ? y0 : t == 1 ? y1 : y2, wl, wh, a0, a1);
+        }
+        acc = glq_reduce96(a0, (uint32_t)a1, (uint32_t)(a1 >> 32));
+    }
+    glq_lane_fence<0>(acc);
+    uint64_t s0 = readlane64(acc, 0);
     uint64_t tk_n = t_round[0];
 #pragma unroll 2
     for (int k = 0; k < N_PARTIAL_ROUNDS; k++) {

@@ -217,6 +217,8 @@ template <class Sink> struct ValBackend {
     template <class WordFn> HF void sponge_observe_words(int n, WordFn word) { if (!sink.sponge_observe_words(cfg.proof, n, word)) fail(3); }
     HF void sponge_observe_cap(uint64_t w0, int n) { if (!sink.sponge_observe_cap(cfg.proof, w0, n, md(), cfg.L)) fail(3); }
     HF Gl sponge_challenge() { return sink.sponge_challenge(); }
+    template <class WordFn> HF void stage_words(int at, int n, WordFn word) { sink.stage_words(cfg.proof, at, n, word); }      // (the sponge's input buffer, while it is idle)
+    HF Gl staged_word(int i) { return sink.staged_word(i); }
     // ---------------------------------------------------------------- strand hooks
     HF bool merkle_split(int q, int kind) {
         if (!cfg.split) return false;

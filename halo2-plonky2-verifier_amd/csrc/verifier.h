@@ -183,9 +183,17 @@ template <class B> struct Verifier {
         // FriChip::verify_fri_proof (fri/mod.rs:446-502): PoW (:130-145), from_os_and_alpha (:45-62)
         be.range_check(pow_response, 64 - s.pow_bits);
         H2W_CLK_MARK("pow range check");
-        cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { return proof_ext(zeta_word(i)); }, fri_alpha);
-        H2W_CLK_MARK("reduced openings 0");
-        cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { return proof_ext(zeta_next_word(i)); }, fri_alpha);
+        if constexpr (B::kDevSponge) {      // (the device prologue wavefront: the opening words side by side into the idle input buffer, not one dependent load each)
+            static_assert(CH_BUF >= 4 * MAX_BATCH_POLYS, "the openings fit the sponge's input buffer");
+            be.stage_words(0, 2 * nz, [&](int j) { return zeta_word(j >> 1) + (uint64_t)(j & 1); });
+            be.stage_words(2 * nz, 2 * nzn, [&](int j) { return zeta_next_word(j >> 1) + (uint64_t)(j & 1); });
+            cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { Ex e; e.e[0] = be.staged_word(2 * i); e.e[1] = be.staged_word(2 * i + 1); return e; }, fri_alpha);
+            H2W_CLK_MARK("reduced openings 0");
+            cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { Ex e; e.e[0] = be.staged_word(2 * nz + 2 * i); e.e[1] = be.staged_word(2 * nz + 2 * i + 1); return e; }, fri_alpha);
+        } else {
+            cb.reduced_openings[0] = ext.reduce_with_powers(nz, [&](int i) { return proof_ext(zeta_word(i)); }, fri_alpha);
+            cb.reduced_openings[1] = ext.reduce_with_powers(nzn, [&](int i) { return proof_ext(zeta_next_word(i)); }, fri_alpha);
+        }
         H2W_CLK_MARK("reduced openings");
     }
     // ---- merkle strand: kind < 3: initial oracle `kind`; kind >= 3: fold step kind-3.  bits/cap_index are wires of the query.

@@ -1,5 +1,6 @@
-// Host check of csrc/glptab.h: the derived tables reproduce plonky2's fast partial rounds (hash/poseidon/permutation.rs:245-262, with
-// mds_partial_layer_init before them) when every round's row sum is kept as an accumulator - the form csrc/glperm.h runs on the device.
+// Host check of csrc/glptab.h: the derived tables reproduce the reference walk from the S-box outputs of the fourth full round to the end of the partial
+// rounds (plonky2 hash/poseidon/permutation.rs: mds_layer, partial_first_constant_layer, mds_partial_layer_init :229-243, the 22 fast partial rounds
+// :245-262) when that stretch is ONE linear layer followed by one accumulator per round - the form csrc/glperm.h runs on the device.
 // g++ -O2 -std=c++17 -I halo2-plonky2-verifier_amd/csrc -I include tests/cpp/glperm_check.cpp
 #include <cstdio>
 #include <cstring>
@@ -14,16 +15,23 @@ int main() {
     int bad = 0;
     for (int trial = 0; trial < 50; trial++) {
         static h2w_poseidon_consts_t k; memset(&k, 0, sizeof k);
-        for (int i = 0; i < 12; i++) { k.mds_circ[i] = trial & 1 ? rnd() : 1 + rnd() % 63; k.mds_diag[i] = i == 0 ? (trial & 1 ? rnd() : 8) : 0; }
+        for (int i = 0; i < 12; i++) { k.mds_circ[i] = trial & 1 ? rnd() : 1 + rnd() % 63; k.mds_diag[i] = i == 0 ? (trial & 1 ? rnd() : 8) : trial % 4 == 3 ? rnd() : 0; k.fast_partial_first_round_constant[i] = rnd(); }
         for (int i = 0; i < 22; i++) k.fast_partial_round_constants[i] = trial == 7 ? GL_P - 1 : rnd();
         for (int i = 0; i < 11; i++) for (int j = 0; j < 11; j++) k.fast_partial_round_initial_matrix[i][j] = rnd();
         for (int i = 0; i < 22; i++) for (int j = 0; j < 11; j++) { k.fast_partial_round_w_hats[i][j] = trial == 7 ? GL_P - 1 - j : rnd(); k.fast_partial_round_vs[i][j] = rnd(); }
         std::vector<uint64_t> aux(GLP_AUX_WORDS); glp_aux_tables(k, aux.data());
-        for (int l = 0; l < 64; l++) if (!(l >= 1 && l < 12) && !(l >= 16 && l < 38) && aux[XO_Q + l] != 0) { printf("Q[%d] not zero\n", l); bad++; }
         for (int kk = 0; kk < N_PARTIAL_ROUNDS; kk++) for (int j = 0; j < kk; j++) if (aux[XO_C + N_PARTIAL_ROUNDS * kk + j] != 0) { printf("C[%d][%d] not zero\n", kk, j); bad++; }
-        uint64_t x[12]; for (int i = 0; i < 12; i++) x[i] = trial == 9 ? GL_P - 1 - i : rnd();
-        // the reference walk
-        uint64_t s[12]; s[0] = x[0];
+        for (int i = 0; i < 12; i++) for (int slot = 0; slot < GLP_SLOTS; slot++) {
+            const uint64_t w = aux[XO_W + i * GLP_SLOTS + slot];
+            if (aux[XO_W + (12 + i) * GLP_SLOTS + slot] != gl_mul(w, 1ull << 22) || aux[XO_W + (24 + i) * GLP_SLOTS + slot] != gl_mul(w, 1ull << 44)) { printf("shifted copy of W[%d][%d]\n", i, slot); bad++; }
+            if (slot == GLP_SLOTS - 1 && (w != 0 || aux[XO_W0 + slot] != 0)) { printf("idle slot not zero\n"); bad++; }
+        }
+        if (glp_slot_of_lane(0) != 0 || glp_slot_of_lane(11) != 11 || glp_slot_of_lane(12) != 34 || glp_slot_of_lane(16) != 12 || glp_slot_of_lane(37) != 33 || glp_slot_of_lane(38) != 34 || glp_slot_of_lane(63) != 34) { printf("slot map\n"); bad++; }
+        uint64_t y[12]; for (int i = 0; i < 12; i++) y[i] = trial == 9 ? GL_P - 1 - i : rnd();
+        // the reference walk: mds_layer, partial_first_constant_layer, mds_partial_layer_init, 22 rounds
+        uint64_t x[12], s[12];
+        for (int r = 0; r < 12; r++) { uint64_t a = gl_mul(y[r], k.mds_diag[r]); for (int i = 0; i < 12; i++) a = gl_muladd(k.mds_circ[i], y[(i + r) % 12], a); x[r] = gl_add(a, k.fast_partial_first_round_constant[r]); }
+        s[0] = x[0];
         for (int c = 1; c < 12; c++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(k.fast_partial_round_initial_matrix[r - 1][c - 1], x[r], a); s[c] = a; }
         const uint64_t m00 = (uint64_t)(k.mds_circ[0] + k.mds_diag[0]) % GL_P;      // (a wrapping u64 sum: chips.h mds_partial_layer_fast)
         for (int r = 0; r < N_PARTIAL_ROUNDS; r++) {
@@ -33,12 +41,10 @@ int main() {
             for (int i = 1; i < 12; i++) s[i] = gl_muladd(k.fast_partial_round_vs[r][i - 1], a, s[i]);
             s[0] = d;
         }
-        // the accumulator form: "lanes" 1..11 hold s_i, "lanes" 16..37 the row sums
-        uint64_t st[12], A[N_PARTIAL_ROUNDS];
-        for (int c = 1; c < 12; c++) { uint64_t a = 0; for (int r = 1; r < 12; r++) a = gl_muladd(k.fast_partial_round_initial_matrix[r - 1][c - 1], x[r], a); st[c] = a; }
-        for (int c = 1; c < 12; c++) st[c] = gl_add(st[c], aux[XO_Q + c]);      // the round constants' share, from the start (lanes 1..11 and 16..37)
-        for (int j = 0; j < N_PARTIAL_ROUNDS; j++) { uint64_t a = aux[XO_Q + 16 + j]; for (int r = 1; r < 12; r++) a = gl_muladd(aux[XO_G + N_PARTIAL_ROUNDS * (r - 1) + j], x[r], a); A[j] = a; }
-        uint64_t s0 = x[0];
+        // the table form: one linear layer onto the 34 slots, then the rounds on s0^7 alone
+        uint64_t out[GLP_SLOTS];
+        for (int slot = 0; slot < GLP_SLOTS; slot++) { uint64_t a = aux[XO_W0 + slot]; for (int i = 0; i < 12; i++) a = gl_muladd(aux[XO_W + i * GLP_SLOTS + slot], y[i], a); out[slot] = a; }
+        uint64_t s0 = out[0], *st = out, *A = out + 12;
         for (int kk = 0; kk < N_PARTIAL_ROUNDS; kk++) {
             const uint64_t a = pow7(s0);      // (no constant: it is in the sums)
             for (int i = 1; i < 12; i++) st[i] = gl_muladd(k.fast_partial_round_vs[kk][i - 1], a, st[i]);

@@ -127,7 +127,8 @@ def test_goldilocks_values_permutation_stays_at_its_instruction_count(tmp_path):
     """glp_permute_lanes (glperm.h: the values phase's Goldilocks permutation, one wavefront, the floor of the prologue): a lone wavefront pays ~4.5 cycles per
     instruction AND per wait state, so the count is the time.  The partial-round loop (two rounds per trip) is four products and two lane swaps a round;
     the function touches memory twice (the list word on the way in, nothing else), never scratch; a row of the MDS layer reads its 24 lane values
-    without a wait state between them (the hand-scheduled block: left to the compiler there were 24)."""
+    without a wait state between them (the hand-scheduled blocks: left to the compiler there were 24); the linear layer before the partial rounds is three
+    such blocks of twelve."""
     lines = _asm("glue.hip", tmp_path)
     lo, hi = _function(lines, "_ZN3h2w17glp_permute_lanes")
     _clean(lines, lo, hi, "Goldilocks values permutation")
@@ -140,8 +141,11 @@ def test_goldilocks_values_permutation_stays_at_its_instruction_count(tmp_path):
     valu = _count(lines, a, b, "v_")
     waits = sum(int(m.group(1)) + 1 for l in lines[a:b + 1] for m in [re.match(r"^\s+s_nop\s+(\d+)", l)] if m)
     assert valu <= 200 and valu + waits <= 240, f"two partial rounds grew to {valu} vector instructions and {waits} wait states"
-    mds = [i for i in range(lo, hi) if re.match(r"^\s+v_readlane_b32 s20, v\d+, 0", lines[i])]
-    assert len(mds) >= 2, "the hand-scheduled MDS rows (first and second half) are gone"
-    for i in mds:
-        blk = lines[i:i + 52]
-        assert sum(1 for l in blk if re.match(r"^\s+v_readlane", l)) == 24 and sum(1 for l in blk[:50] if re.match(r"^\s+s_nop", l)) == 0
+    starts = [i for i in range(lo, hi) if re.match(r"^\s+v_readlane_b32 s20, v\d+, 0", lines[i])]
+    ends = [next(j for j in range(i, hi + 1) if "#ASMEND" in lines[j]) for i in starts]
+    rows = [sum(1 for l in lines[i:e] if re.match(r"^\s+v_readlane", l)) for i, e in zip(starts, ends)]
+    assert rows.count(24) >= 2, "the hand-scheduled MDS rows (first and second half) are gone"
+    assert rows.count(12) == 3, "the three limb passes of the linear layer before the partial rounds (glq_dense12) are gone"
+    for i, e in zip(starts, ends):
+        last = max(j for j in range(i, e) if re.match(r"^\s+v_readlane", lines[j]))
+        assert sum(1 for l in lines[i:last] if re.match(r"^\s+s_nop", l)) == 0, "a wait state between the v_readlanes of a hand-scheduled block"

@@ -15,7 +15,7 @@ using namespace h2w;
 template <int V> __global__ void k_perm(const h2w_poseidon_consts_t *k, uint64_t *io, int n, long long *cyc, int small) {
     stage_glp_consts<true>(k, threadIdx.x, 64);
     const int lane = threadIdx.x;
-    uint64_t x = lane < SPONGE_WIDTH ? io[lane] : 0;
+    uint64_t x = (lane & 15) < SPONGE_WIDTH ? io[lane & 15] : 0;      // every 16-lane row alike
     const long long t0 = clock64();
     for (int i = 0; i < n; i++) {
         x = glp_permute_lanes(x, (lds64_t *)s_glp_k, (lds64_t *)s_glp_m, (lds64_t *)s_glp_x, lane, small != 0);
