@@ -125,30 +125,6 @@ template <bool COLS> __global__ __launch_bounds__(64) void k_glp_emit(BatchArgs 
     sink.coop_poseidon_permute(st, A.consts);
 }
 
-// Goldilocks-Poseidon Merkle strands (hash_mode 0), values phase: one wavefront per (owned unit, kind); blockIdx.y = kind slot
-template <bool COLS> __global__ __launch_bounds__(64) void k_merkle_gl_values(BatchArgs A) {
-    typedef CoopSinkT<COLS, true, 0> Sink; typedef ValBackend<Sink> CoopB;
-    __builtin_amdgcn_s_setprio(3);
-    stage_glp_consts<true>(A.consts, threadIdx.x, 64);
-    int p, q;
-    if (!own_unit_at(A, blockIdx.x, p, q)) return;
-    const int sq = q == 0 ? 0 : 1;
-    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
-    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
-    Sink sink; coop_sink_init(sink, A, p, q); sink.emit = true;
-    sink.nrec = strand_q_rec(*A.st, q) + A.st->mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(*A.st, q) + A.st->mk_cell_rel[sq][kind];
-    sink.glp_slot = A.st->pro_nglp + (uint32_t)q * A.st->q_nglp + A.st->mk_glp_rel[kind];
-    CoopB be(sink, make_cfg(A, p), true);
-    const h2w_shape_t shp = A.shape;      // (a reference into the kernel arguments would put all of them on every lane's stack)
-    Verifier<CoopB> V(be, shp, A.consts);
-    const uint64_t x = A.cbs[p].fri_query_indices[q];
-    const int lde = V.d.lde_bits; int lo = 0;
-    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
-    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
-    V.merkle_strand(q, kind, PackedBits{x, lo}, lde - lo, cap_index);
-    if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
-}
-
 // between the two passes: the S-box values of the owned units' partial rounds, as the values pass left them (times R), to the canonical
 // values the emission shows - one lane per value, 168 per permutation unit
 __global__ __launch_bounds__(256) void k_sbox_canon(BatchArgs A, uint32_t units_per_query) {
@@ -593,7 +569,7 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
         if (p->shape.hash_mode == 0) {
             if (cstream != stream) { H2W_HIP(hipStreamWaitEvent(cstream, ev[9], 0)); forked = true; }
             H2W_HIP(hipEventRecord(ev[4], cstream));
-            if (nunits) { if (cm.starts) hipLaunchKernelGGL(k_merkle_gl_values<true>, dim3(nunits, nkinds), dim3(64), 0, cstream, A); else hipLaunchKernelGGL(k_merkle_gl_values<false>, dim3(nunits, nkinds), dim3(64), 0, cstream, A); }
+            if (nunits) launch_merkle_gl_values(A, nunits, nkinds, cstream);
             H2W_HIP(hipEventRecord(ev[10], cstream)); H2W_HIP(hipEventRecord(ev[5], cstream));
         }
         if (nunits) launch_glue_strands(A, stream);

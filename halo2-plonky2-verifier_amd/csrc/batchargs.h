@@ -110,5 +110,6 @@ void launch_merkle_bn_emit(const BatchArgs &A, dim3 grid, hipStream_t stream);  
 void launch_merkle_bn_values(const BatchArgs &A, dim3 grid, hipStream_t stream);    // glue.hip
 void launch_merkle_bn_values_row(const BatchArgs &A, unsigned nkinds, hipStream_t stream);    // glue.hip
 void launch_prologue_values(const BatchArgs &A, hipStream_t stream);   // glue.hip
+void launch_merkle_gl_values(const BatchArgs &A, unsigned nunits, unsigned nkinds, hipStream_t stream);   // glue.hip
 
 }  // namespace h2w

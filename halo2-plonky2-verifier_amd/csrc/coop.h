@@ -193,7 +193,12 @@ template <bool COLS, bool VALPH = false, int HASH_MODE = -1> struct CoopSinkT {
         return readlane64(sx, --sp_out);
     }
 
-    __device__ __noinline__ void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
+#if defined(H2W_FLATTEN_CHIPS)      // (glue.hip: the values strands, flattened - the state array stays in registers)
+    __device__ __forceinline__
+#else
+    __device__ __noinline__
+#endif
+    void coop_poseidon_permute(uint64_t *st, const h2w_poseidon_consts_t *) {
         if constexpr (VALPH) {
             // values phase: list the permutation (lane 0: where its records start; lanes 1..12: the input state), compute its output
             uint64_t w = nrec, x = 0;

@@ -175,6 +175,34 @@ void launch_merkle_bn_emit(const BatchArgs &A, dim3 grid, hipStream_t stream) {
     else hipLaunchKernelGGL(k_merkle_bn_emit<false>, grid, dim3(QUAD_BLOCK), 0, stream, A);
 }
 
+// Goldilocks-Poseidon Merkle strands (hash_mode 0), values phase: one wavefront per (owned unit, kind); blockIdx.y = kind slot.  Flattened like the
+// prologue (round 4): out of line, every hash of a path handed its state to the permutation through scratch memory and the sink lived there
+template <bool COLS> __global__ __launch_bounds__(64) __attribute__((flatten)) void k_merkle_gl_values(BatchArgs A) {
+    typedef CoopSinkT<COLS, true, 0> Sink; typedef ValBackend<Sink> CoopB;
+    __builtin_amdgcn_s_setprio(3);
+    stage_glp_consts<true>(A.consts, threadIdx.x, 64);
+    int p, q;
+    if (!own_unit_at(A, blockIdx.x, p, q)) return;
+    const int sq = q == 0 ? 0 : 1;
+    const int n_or = A.shape.n_perm_z > 0 ? 3 : 2;
+    const int slot = blockIdx.y, kind = slot < n_or ? slot : 3 + (slot - n_or);
+    Sink sink; coop_sink_init(sink, A, p, q); sink.emit = true;
+    sink.nrec = strand_q_rec(*A.st, q) + A.st->mk_rec_rel[sq][kind]; sink.cell_off = strand_q_cell(*A.st, q) + A.st->mk_cell_rel[sq][kind];
+    sink.glp_slot = A.st->pro_nglp + (uint32_t)q * A.st->q_nglp + A.st->mk_glp_rel[kind];
+    CoopB be(sink, make_cfg(A, p), true);
+    const h2w_shape_t shp = A.shape;      // (a reference into the kernel arguments would put all of them on every lane's stack)
+    Verifier<CoopB> V(be, shp, A.consts);
+    const uint64_t x = A.cbs[p].fri_query_indices[q];
+    const int lde = V.d.lde_bits; int lo = 0;
+    if (kind >= 3) for (int i = 0; i <= kind - 3; i++) lo += V.d.arity[i];
+    const uint64_t cap_index = (x >> (lde - A.shape.cap_height)) & ((1ull << A.shape.cap_height) - 1);
+    V.merkle_strand(q, kind, PackedBits{x, lo}, lde - lo, cap_index);
+    if (threadIdx.x == 0 && be.status) atomicCAS(&A.status[p], 0u, be.status);
+}
+
+void launch_merkle_gl_values(const BatchArgs &A, unsigned nunits, unsigned nkinds, hipStream_t stream) {
+    if (A.cm.starts) hipLaunchKernelGGL(k_merkle_gl_values<true>, dim3(nunits, nkinds), dim3(64), 0, stream, A); else hipLaunchKernelGGL(k_merkle_gl_values<false>, dim3(nunits, nkinds), dim3(64), 0, stream, A);
+}
 void launch_prologue_values(const BatchArgs &A, hipStream_t stream) {
     if (A.cm.starts) hipLaunchKernelGGL(k_prologue_values<true>, dim3((unsigned)A.nproofs), dim3(64), 0, stream, A);
     else hipLaunchKernelGGL(k_prologue_values<false>, dim3((unsigned)A.nproofs), dim3(64), 0, stream, A);
