@@ -349,7 +349,8 @@ int h2w_plan_configure(h2w_plan *, int option, int value);
  * chains, values + emission (0 with Goldilocks-Poseidon caps), ms[3] = expansion kernel, ms[4] = whole call.
  * `back` = how many batch calls before the last one (a ring of the last 64 is kept).  Blocks until that batch finished. */
 int h2w_plan_timing(h2w_plan *, uint64_t back, float ms[5]);
-/* The same per kernel: ms[0] k_prologue_values, ms[1] k_glp_emit (records of the listed Goldilocks-Poseidon permutations), ms[2] k_strands
+/* The same per kernel: ms[0] k_prologue_values (alone: the witness-load kernel k_prologue_load runs BEHIND it, beside the Merkle chains - nothing waits for its
+ * cells - and is part of ms[6] only), ms[1] k_glp_emit (records of the listed Goldilocks-Poseidon permutations), ms[2] k_strands
  * (+ k_merkle_gl_values), ms[3] k_merkle_bn_values (one pass: k_merkle_bn_fused), ms[4] k_merkle_bn_emit, ms[5] expansion kernel, ms[6] whole call,
  * ms[7] = the H2W_OPT_CHAIN_PASSES the call ran with (PoseidonBN254 caps; else 0). */
 int h2w_plan_timing_ex(h2w_plan *, uint64_t back, float ms[8]);
