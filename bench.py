@@ -504,10 +504,22 @@ def _main():
         t3 = time.perf_counter()
         eager = {"workload": f"{args.config}, PoseidonBN254 caps: h2w_chip_verify_stark = the gadget stack over nothing but the level-1 / level-2 C ABI (one call per NativeChip / GoldilocksChip operation)",
                  "cells": ctx.num_cells(), "value": ctx.num_cells() / (t3 - t1), "unit": "cells/s", "host_seconds": t2 - t1, "expand_seconds": t3 - t2, "advice_on": "device" if ptr else None}
+        fp = ctx.footprint()
         ctx.reset()                      # the next proof through the same context: its host vectors are sized and mapped (h2w_ctx_reset)
         t1 = time.perf_counter()
         api.verify_stark(ctx, shape, consts, hp)
         eager["host_seconds_reused_context"] = time.perf_counter() - t1
+        ctx.close()
+        # a NEW context whose vectors were sized and mapped ahead (h2w_ctx_reserve with the footprint of an earlier run of the shape): what the first proof of a
+        # service costs once the faults are taken out of the run (reserve_seconds: taking them, ahead of time)
+        ctx = api.Context(args.lookup_bits, True, local_rank)
+        t0 = time.perf_counter()
+        ctx.reserve(*fp)
+        t1 = time.perf_counter()
+        api.verify_stark(ctx, shape, consts, hp)
+        eager["host_seconds_reserved_context"] = time.perf_counter() - t1
+        eager["reserve_seconds"] = t1 - t0
+        eager["footprint"] = {"records": fp[0], "literal_cells": fp[1]}
         ctx.close()
         # record and replay (include/h2w.h 2d): the SAME operator-level run recorded once (trace mode), lowered by h2w_plan_from_trace, and replayed by
         # h2w_fri_witness_batch on the other proofs of the step - the reference's circuit as its own chips drive it, at GPU speed, with no hand-restated

@@ -120,6 +120,8 @@ SYMBOLS = {
     "h2w_gl_ext_inv_witness": (C.c_int, [_vp, _av, _av]),
     "h2w_ctx_trace_begin": (C.c_int, [_vp]),
     "h2w_ctx_reset": (C.c_int, [_vp]),
+    "h2w_ctx_footprint": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "h2w_ctx_reserve": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "h2w_trace_input": (C.c_int, [_vp, C.c_uint64, C.c_uint32]),
     "h2w_plan_from_trace": (_vp, [_vp, C.c_uint64, C.POINTER(C.c_char_p), C.c_size_t, C.c_int]),
     "h2w_chip_ext_op": (C.c_int, [_vp, C.c_int, _av, _av, _av, _av]),

@@ -27,6 +27,16 @@ class Context:
         """The context as new, its host memory kept (h2w_ctx_reset): for the next proof's run."""
         _ck(self.L.h2w_ctx_reset(self.p), "h2w_ctx_reset")
 
+    def footprint(self):
+        """(block records, literal cells) the run so far appended (h2w_ctx_footprint): the sizes for `reserve` on a new context."""
+        out = (C.c_uint64 * 2)()
+        _ck(self.L.h2w_ctx_footprint(self.p, out), "h2w_ctx_footprint")
+        return int(out[0]), int(out[1])
+
+    def reserve(self, n_records, n_literal_cells):
+        """Host vectors of a NEW context sized and mapped ahead of its first run (h2w_ctx_reserve)."""
+        _ck(self.L.h2w_ctx_reserve(self.p, n_records, n_literal_cells), "h2w_ctx_reserve")
+
     def trace_begin(self):
         """Record the op tape of this context's run (h2w_ctx_trace_begin; Plan.from_trace turns it into a replayable plan)."""
         _ck(self.L.h2w_ctx_trace_begin(self.p), "h2w_ctx_trace_begin")

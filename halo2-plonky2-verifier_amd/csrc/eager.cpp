@@ -236,6 +236,26 @@ int h2w_ctx_reset(h2w_ctx *c) {
     delete c->trace; c->trace = nullptr;
     return 0;
 }
+int h2w_ctx_footprint(const h2w_ctx *c, uint64_t out[2]) {
+    if (!c || !out) { set_error("h2w_ctx_footprint: null argument"); return -1; }
+    out[0] = c->recs.size(); out[1] = c->pool.size();
+    return 0;
+}
+// A new context's vectors sized AND mapped ahead of a run (the pages are touched here, once each, instead of faulting one by one under the first run's appends)
+int h2w_ctx_reserve(h2w_ctx *c, uint64_t n_records, uint64_t n_literal_cells) {
+    if (!check(c, "h2w_ctx_reserve")) return -1;
+    if (n_records > (1ull << 34) || n_literal_cells > (1ull << 34)) { set_error("h2w_ctx_reserve: more than 2^34 entries"); return -1; }
+    auto map = [](auto &v, uint64_t n) {
+        if (v.capacity() >= n) return;
+        const size_t had = v.capacity();
+        v.reserve((size_t)n);
+        volatile char *b = reinterpret_cast<volatile char *>(v.data());
+        const size_t lo = (had * sizeof(v[0])) & ~(size_t)4095, hi = v.capacity() * sizeof(v[0]);
+        for (size_t i = lo < v.size() * sizeof(v[0]) ? v.size() * sizeof(v[0]) : lo; i < hi; i += 4096) b[i] = 0;      // (beyond size(): capacity the appends will fill)
+    };
+    map(c->meta, n_records); map(c->recs, n_records); map(c->pool, n_literal_cells);
+    return 0;
+}
 uint64_t h2w_num_cells(const h2w_ctx *c) { return c ? c->ncells : 0; }
 int h2w_ctx_error(const h2w_ctx *c) { return c ? c->err : 1; }
 

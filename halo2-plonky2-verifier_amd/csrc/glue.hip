@@ -46,7 +46,7 @@ struct RowSink {
     __device__ void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     __device__ __forceinline__ bool level_skip(fr_t &, bool &) { return false; }
     __device__ __forceinline__ bool tail_skip() const { return true; }      // the cap lookup: cells only (no value anyone uses)
-    __device__ __noinline__ void permute_unit(fr_t *st) {
+    __device__ __forceinline__ void permute_unit(fr_t *st) {
         rf::RowConst K;
         {   // wave-uniform: scalar loads
             const uint32_t *src = reinterpret_cast<const uint32_t *>(rowk); uint32_t *dst = reinterpret_cast<uint32_t *>(&K);

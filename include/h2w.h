@@ -94,6 +94,10 @@ int         h2w_poseidon_published(h2w_poseidon_consts_t *out);
 h2w_ctx *h2w_ctx_new(int lookup_bits, int witness_gen_only, int device_id);   /* base_test().k(k): lookup_bits = k-1 */
 void     h2w_ctx_free(h2w_ctx *);
 int      h2w_ctx_reset(h2w_ctx *);                                              /* the context as new, its host memory kept (the next proof's run does not fault its pages in again) */
+int      h2w_ctx_footprint(const h2w_ctx *, uint64_t out[2]);                    /* what the run so far appended: out[0] block records, out[1] literal cells (32 B each) */
+int      h2w_ctx_reserve(h2w_ctx *, uint64_t n_records, uint64_t n_literal_cells); /* Vec::with_capacity for a NEW context: its host vectors sized and mapped ahead (a cfg-3 PoseidonBN254
+                                                                                  * proof appends 350 MB; on a fresh context two thirds of a level-1 run are first-touch faults and
+                                                                                  * reallocation copies).  Sizes: h2w_ctx_footprint of an earlier run of the same shape */
 uint64_t h2w_num_cells(const h2w_ctx *);                                        /* util/context_wrapper.rs:24-26 */
 int      h2w_ctx_error(const h2w_ctx *);                                        /* sticky error flag of the context */
 /* scoped cell counters: what the reference's #[count] proc-macro (macro/src/lib.rs:9-61) drives through

@@ -124,6 +124,16 @@ impl<F: BigPrimeField> Context<F> {
     pub fn reset(&mut self) {
         ck(unsafe { h2w_ctx_reset(self.h2w) });
     }
+    /// (block records, literal cells) the run so far appended: the sizes for `reserve` on a new context of the same shape
+    pub fn footprint(&self) -> (u64, u64) {
+        let mut out = [0u64; 2];
+        ck(unsafe { h2w_ctx_footprint(self.h2w, out.as_mut_ptr()) });
+        (out[0], out[1])
+    }
+    /// Vec::with_capacity for a new context: its host vectors sized and mapped ahead of the first run
+    pub fn reserve(&mut self, n_records: u64, n_literal_cells: u64) {
+        ck(unsafe { h2w_ctx_reserve(self.h2w, n_records, n_literal_cells) });
+    }
     // ---- record and replay (include/h2w.h 2d): ONE run of the unchanged chips on this context becomes a plan the GPU replays
     /// start recording the op tape (on a fresh context)
     pub fn trace_begin(&mut self) {

@@ -145,6 +145,32 @@ def test_context_reset_is_a_fresh_context_with_its_memory(h2w, h2w_api):
     ctx.close()
 
 
+def test_context_reserve_sizes_a_new_context_and_changes_nothing_else(h2w, h2w_api):
+    """h2w_ctx_footprint / h2w_ctx_reserve: the footprint of a run sizes a NEW context ahead of the same run; records and cells are what they were, reserving
+    again (or less) is a no-op, an absurd size is refused."""
+    def run(ctx):
+        native = h2w_api.NativeChip(ctx); chip = h2w_api.GoldilocksChip(native)
+        a = chip.load_witness(0xFFFFFFFF00000000); b = chip.load_constant(12345)
+        for _ in range(300):
+            a = chip.mul_add(a, b, a)
+        w = native.load_witness(2**200 + 5)        # values beyond 64 bits: literal cells
+        for _ in range(20):
+            w = native.mul(w, w)
+        return ctx.num_cells(), ctx.footprint(), (bytes(a.value), bytes(w.value))
+    c1 = h2w_api.Context(21, True, 0)
+    n1, fp1, v1 = run(c1)
+    assert fp1[0] > 0 and fp1[1] > 0
+    c2 = h2w_api.Context(21, True, 0)
+    assert c2.footprint() == (0, 0)
+    c2.reserve(*fp1); c2.reserve(1, 1); c2.reserve(4 * fp1[0], 4 * fp1[1])
+    assert c2.footprint() == (0, 0) and c2.num_cells() == 0
+    n2, fp2, v2 = run(c2)
+    assert (n2, fp2, v2) == (n1, fp1, v1)
+    with pytest.raises(h2w.H2WError):
+        c2.reserve(1 << 40, 1)
+    c1.close(); c2.close()
+
+
 def test_product_library_has_no_experiment_switches(h2w):
     """No experiment switches exist in the sources any more (round 1 shipped wrong-output kernel variants behind getenv): kernel variants are
     local patches / compile-time flags built as a separately named library by tools/experiments/variant.sh, and the library the tests, smoke()

@@ -94,7 +94,7 @@ def test_row_cooperative_values_pass_round_loops(tmp_path):
     flat access and without a vector-memory wait (its only memory traffic are the three S-box stores); its table entries are read a round ahead (the LDS reads
     stand at the top of the loop); it stays near the instruction count its 1.3 ms correspond to."""
     glue = _asm("glue.hip", tmp_path)
-    lo, hi = _function(glue, "_ZN3h2w7RowSink12permute_unit")
+    lo, hi = _function(glue, "_ZN3h2w22k_merkle_bn_values_row")      # (permute_unit is inlined into the flattened kernel since round 4: no call, no entry wait for the previous unit's state store)
     loops = list(_loops(glue, lo, hi))
     partial = [(a, b) for a, b in loops if 85 <= _count(glue, a, b, "v_mad_u64_u32") <= 90]
     assert partial, "partial-round loop (three products of 29 multiply-adds) not found"

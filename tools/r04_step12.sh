@@ -14,5 +14,5 @@ timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_a
 python3 - <<'P'
 import json
 d=json.loads(open('gpurun_out/r04_bench_after_selarr.json').read().strip().split('\n')[-1])
-print({k:d[k] for k in ('value','ms_per_step')}, d.get('latency'), d.get('kernel_ms_isolated'), d.get('secondary',{}).get('value'), d.get('eager',{}).get('replay'))
+e=d.get('eager') or {}; print({k:d[k] for k in ('value','ms_per_step')}, d.get('latency'), d.get('kernel_ms_isolated'), d.get('secondary',{}).get('value'), {k:v for k,v in e.items() if 'seconds' in k or k=='footprint'}, (e.get('replay') or {}).get('value'))
 P
