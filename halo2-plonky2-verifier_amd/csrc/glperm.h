@@ -2,12 +2,16 @@
 //
 // A wavefront that has its SIMD to itself issues one instruction every ~4 cycles, a wait state (s_nop) costs the same 4 cycles, and a DEPENDENT
 // instruction waits ~9 (tools/ubench/ubench_wave1.hip, profiles/r04_ubench_wave1.txt): a permutation that is one dependent chain is priced by its
-// instruction count.  Three things keep that count down:
+// instruction count.  What keeps that count down:
 //   * the reduction of a 128-bit product (glq_reduce) is written in assembly: one v_mad_u64_u32 folds the 2^64 word, its carry and the borrow of the
 //     2^96 word are turned into ONE 64-bit correction (20 instructions and 3 wait states per product; the compiler's compare-and-select form: 25 and 5);
 //   * the four 16-lane rows mirror each other, so x^3 (even rows) and x^4 (odd rows) are ONE product and v_permlane16_swap brings them together;
-//   * a full round's constant layer is folded into the MDS sums of the round before it, and the row sum of a partial round is formed beside its S-box
-//     from 22-bit limbs with v_add_u32 DPP (no carries, no wait states) instead of after it from 64-bit values.
+//   * a row of the small-entry MDS matrix is one hand-scheduled block (24 v_readlane, 24 v_mad_u64_u32, one reduction), with the next round's constant
+//     layer in its sums;
+//   * the partial rounds keep one accumulator per round instead of forming a row sum per round (glptab.h): a round is the S-box of one value and one
+//     multiply-add per lane;
+//   * the stretch from the fourth S-box layer to the partial rounds' lanes is ONE linear layer whose entries the host composed (glptab.h W): 36 products
+//     of 22-bit limbs into two sums, one reduction.
 // Values are ANY 64-bit representatives (x mod p for some x < 2^64) between operations; the permutation's output is canonical.
 #pragma once
 
@@ -83,9 +87,6 @@ __device__ __forceinline__ uint64_t glq_bcast_row0(uint64_t v) {
     lo = __builtin_amdgcn_permlane32_swap(lo[0], lo[0], false, false);                                  // [v0 v0 v0 v0]
     hi = __builtin_amdgcn_permlane32_swap(hi[0], hi[0], false, false);
     return ((uint64_t)hi[0] << 32) | lo[0];
-}
-template <int N> __device__ __forceinline__ uint32_t glq_shl_add(uint32_t v) {      // lane i: v_i + v_{i+N} of its row (0 beyond the row): v_add_u32 with a DPP operand
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
 }
 
 // One row of a small-entry MDS matrix times the state on the lanes, plus a constant word: sum_j m_j s_j + next, s_j = lane j's x (v_readlane), as two
