@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4: after the strand objects left scratch memory (chips.h SelArr): per-kernel times of one launch, the GPU suite, the default bench
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 O=gpurun_out/r04_after_selarr.txt
 : > $O
