@@ -58,3 +58,15 @@ def test_partial_round_accumulator_tables_reproduce_the_fast_partial_rounds(tmp_
                     os.path.join(ROOT, "tests", "cpp", "glperm_check.cpp"), "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_assembly_reductions_restated_on_the_host(tmp_path):
+    """csrc/glperm.h glq_reduce / glq_reduce96 (written in assembly for the device) restated instruction by instruction in integer arithmetic: the algorithm -
+    one multiply-add folds the 2^64 word, its carry and the 2^96 word's borrow become one correction, no second wrap - against x mod p on edge values, on the rare
+    borrow and carry-and-borrow cases, on products and on the sums of the MDS / linear layers."""
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = os.path.join(str(tmp_path), "glq_reduce_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "glq_reduce_check.cpp"), "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
