@@ -71,6 +71,31 @@ template <int T> __global__ void k_op(uint64_t *o, int n, long long *cyc) {
     const long long t1 = clock64();
     o[128 + threadIdx.x] = x + y + z; if (threadIdx.x == 0) *cyc = t1 - t0;
 }
+
+// U: four INDEPENDENT chains of one instruction type (what the instruction costs to issue when the wavefront has other work between dependent uses):
+// 0 v_add_u32 | 1 v_mad_u64_u32 | 2 v_fma_f64 | 3 v_mul_lo_u32 | 4 v_mul_hi_u32 | 5 v_mad_u32_u24 | 6 v_mov_b32_dpp (row_shr:1) | 7 v_cvt_f64_u32 | 8 v_lshl_add_u64
+template <int U> __global__ void k_ilp(uint64_t *o, int n, long long *cyc) {
+    uint32_t x0 = (uint32_t)o[threadIdx.x], x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, y = (uint32_t)o[threadIdx.x + 64] | 1;
+    uint64_t z0 = o[threadIdx.x], z1 = z0 + 1, z2 = z0 + 2, z3 = z0 + 3, zy = o[threadIdx.x + 64];
+    double d0 = (double)x0, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, dy = 1.0000001;
+    const long long t0 = clock64();
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (U == 0) asm volatile("v_add_u32_e32 %0, %0, %4\n\tv_add_u32_e32 %1, %1, %4\n\tv_add_u32_e32 %2, %2, %4\n\tv_add_u32_e32 %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y));
+            if (U == 1) asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3) : "v"(x0), "v"(y) : "vcc");
+            if (U == 2) asm volatile("v_fma_f64 %0, %0, %4, %0\n\tv_fma_f64 %1, %1, %4, %1\n\tv_fma_f64 %2, %2, %4, %2\n\tv_fma_f64 %3, %3, %4, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dy));
+            if (U == 3) asm volatile("v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y));
+            if (U == 4) asm volatile("v_mul_hi_u32 %0, %0, %4\n\tv_mul_hi_u32 %1, %1, %4\n\tv_mul_hi_u32 %2, %2, %4\n\tv_mul_hi_u32 %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y));
+            if (U == 5) asm volatile("v_mad_u32_u24 %0, %0, %4, %0\n\tv_mad_u32_u24 %1, %1, %4, %1\n\tv_mad_u32_u24 %2, %2, %4, %2\n\tv_mad_u32_u24 %3, %3, %4, %3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y));
+            if (U == 6) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %3, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            if (U == 7) asm volatile("v_cvt_f64_u32_e32 %0, %4\n\tv_cvt_f64_u32_e32 %1, %5\n\tv_cvt_f64_u32_e32 %2, %6\n\tv_cvt_f64_u32_e32 %3, %7" : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+            if (U == 8) asm volatile("v_lshl_add_u64 %0, %0, 0, %4\n\tv_lshl_add_u64 %1, %1, 0, %4\n\tv_lshl_add_u64 %2, %2, 0, %4\n\tv_lshl_add_u64 %3, %3, 0, %4" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3) : "v"(zy));
+        }
+    }
+    const long long t1 = clock64();
+    o[128 + threadIdx.x] = x0 + x1 + x2 + x3 + z0 + z1 + z2 + z3 + (uint64_t)(d0 + d1 + d2 + d3); if (threadIdx.x == 0) *cyc = t1 - t0;
+}
 static uint64_t h_mul(uint64_t a, uint64_t b) { return (uint64_t)(((u128)(a % GL_P) * (b % GL_P)) % GL_P); }
 int main() {
     uint64_t *o; long long *cyc; CK(hipMalloc(&o, 256 * 8)); CK(hipMalloc(&cyc, 8));
@@ -108,6 +133,18 @@ int main() {
         }
         float ms; hipEventElapsedTime(&ms, e0, e1); long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
         printf("%-26s %.2f ns = %.2f ticks per group\n", names[T], ms * 1e6 / (16.0 * n), (double)c / (16.0 * n));
+    }
+    const char *unames[] = {"v_add_u32", "v_mad_u64_u32", "v_fma_f64", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mov_b32_dpp", "v_cvt_f64_u32", "v_lshl_add_u64"};
+    for (int U = 0; U < 9; U++) {
+        for (int rep = 0; rep < 2; rep++) {
+            switch (U) {
+#define D(i) case i: hipLaunchKernelGGL(k_ilp<i>, dim3(1), dim3(64), 0, 0, o, n, cyc); break;
+                D(0) D(1) D(2) D(3) D(4) D(5) D(6) D(7) D(8)
+            }
+            CK(hipDeviceSynchronize());
+        }
+        long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+        printf("four independent chains of %-16s %.2f ticks per instruction\n", unames[U], (double)c / (16.0 * n));
     }
     return 0;
 }
