@@ -55,7 +55,7 @@ template <int T> __global__ void k_op(uint64_t *o, int n, long long *cyc) {
     const long long t0 = clock64();
     for (int i = 0; i < n; i++) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < 64; j++) {      // (64 per trip: the trip itself - scalar bookkeeping and a taken branch - is ~40 ticks)
             if (T == 0) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(x) : "v"(y));
             if (T == 1) asm volatile("v_add_u32_e32 %0, %0, %1\n\ts_nop 0" : "+v"(x) : "v"(y));
             if (T == 2) asm volatile("v_add_u32_e32 %0, %0, %1\n\ts_nop 1" : "+v"(x) : "v"(y));
@@ -81,7 +81,7 @@ template <int U> __global__ void k_ilp(uint64_t *o, int n, long long *cyc) {
     const long long t0 = clock64();
     for (int i = 0; i < n; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 16; j++) {      // (64 instructions per trip)
             if (U == 0) asm volatile("v_add_u32_e32 %0, %0, %4\n\tv_add_u32_e32 %1, %1, %4\n\tv_add_u32_e32 %2, %2, %4\n\tv_add_u32_e32 %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(y));
             if (U == 1) asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3) : "v"(x0), "v"(y) : "vcc");
             if (U == 2) asm volatile("v_fma_f64 %0, %0, %4, %0\n\tv_fma_f64 %1, %1, %4, %1\n\tv_fma_f64 %2, %2, %4, %2\n\tv_fma_f64 %3, %3, %4, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dy));
@@ -132,7 +132,7 @@ int main() {
             hipEventRecord(e1); CK(hipDeviceSynchronize());
         }
         float ms; hipEventElapsedTime(&ms, e0, e1); long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
-        printf("%-26s %.2f ns = %.2f ticks per group\n", names[T], ms * 1e6 / (16.0 * n), (double)c / (16.0 * n));
+        printf("%-26s %.2f ns = %.2f ticks per group\n", names[T], ms * 1e6 / (64.0 * n), (double)c / (64.0 * n));
     }
     const char *unames[] = {"v_add_u32", "v_mad_u64_u32", "v_fma_f64", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mov_b32_dpp", "v_cvt_f64_u32", "v_lshl_add_u64"};
     for (int U = 0; U < 9; U++) {
@@ -144,7 +144,7 @@ int main() {
             CK(hipDeviceSynchronize());
         }
         long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
-        printf("four independent chains of %-16s %.2f ticks per instruction\n", unames[U], (double)c / (16.0 * n));
+        printf("four independent chains of %-16s %.2f ticks per instruction\n", unames[U], (double)c / (64.0 * n));
     }
     return 0;
 }
