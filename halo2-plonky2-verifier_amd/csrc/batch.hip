@@ -194,7 +194,7 @@ namespace h2w {
 // a traced plan (replay.hip)
 uint64_t traced_workspace_bytes(const h2w_plan *p, uint64_t n);
 uint64_t traced_status_offset(const h2w_plan *p, uint64_t n, bool flags);
-int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_);
+int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, ColMap cm, uint64_t cell_stride);
 void traced_free(h2w_plan *p);
 PlanEqualities &plan_equalities(h2w_plan *p) { return p->eqs; }
 const h2w_shape_t &plan_shape(const h2w_plan *p) { return p->shape; }
@@ -467,9 +467,9 @@ static int run_batch(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs,
     if (p->device < 0) { set_error("h2w_fri_witness_batch: no HIP device — the hot path only runs on the GPU (no CPU fallback)"); return -1; }
     if (!proofs_dev || !advice_dev || !workspace_dev) { set_error("h2w_fri_witness_batch: null buffer"); return -1; }
     if (n_proofs == 0) return 0;
-    if (p->traced) {      // a recorded run (replay.hip): the flat stream, unsharded
-        if (cm.starts || sh.world > 1 || emit_stream_ != stream_) { set_error("h2w_fri_witness_batch: a traced plan writes the flat advice stream on one stream, unsharded"); return -1; }
-        return traced_run(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_);
+    if (p->traced) {      // a recorded run (replay.hip): the flat stream or the FlexGate columns, unsharded
+        if (sh.world > 1 || emit_stream_ != stream_) { set_error("h2w_fri_witness_batch: a traced plan runs on one stream, unsharded"); return -1; }
+        return traced_run(p, proofs_dev, n_proofs, advice_dev, workspace_dev, stream_, cm, cell_stride);
     }
     if (n_proofs * (uint64_t)p->shape.num_queries * (p->st.mk_item0[MK_KINDS] ? p->st.mk_item0[MK_KINDS] : 1) > 0x3fffffffull) { set_error("h2w_fri_witness_batch: batch too large"); return -1; }
     if (n_proofs > 65535) { set_error("h2w_fri_witness_batch: more than 65535 proofs per call (the proof index is a grid dimension of the load and expansion kernels); split the batch"); return -1; }

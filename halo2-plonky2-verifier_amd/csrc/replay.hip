@@ -76,7 +76,7 @@ struct TmplD { uint32_t tape0, nslots, ninst, inst0, depth; };
 
 struct ReplayArgs {
     const uint32_t *tape; const InstD *insts; const ImpD *imps; const uint32_t *inputs; const uint64_t *pool64; const fr_t *poolfr;
-    const uint64_t *proofs; uint64_t proof_words; rec_t *recs; uint64_t rec_stride; fr_t *out; uint64_t cell_stride; uint64_t *vals; uint32_t *status;
+    const uint64_t *proofs; uint64_t proof_words; rec_t *recs; uint64_t rec_stride; fr_t *out; uint64_t cell_stride; ColMap cm; uint64_t *vals; uint32_t *status;
     const uint16_t *ncells; const fr_t *inv_pos, *inv_neg; FrParams P; int L; uint32_t nproofs;
     uint32_t depth, ntmpl, npool64, npoolfr;
     const TmplD *tm; const uint64_t *prefix;      // per template (device tables of the plan): its description; the u64 elements per proof of the value stores before it
@@ -96,8 +96,9 @@ struct ReplaySink {
     static constexpr bool kCoop = false, kSplitOnly = false, kBnUnits = false, kDevSponge = false; static constexpr int kHashMode = -1;
     HF void coop_poseidon_permute(uint64_t *, const h2w_poseidon_consts_t *) {}
     rec_t *recs; uint64_t nrec; fr_t *out; uint64_t cell_off; const uint32_t *ncells;      // ncells: an LDS table (a global load per record would wait for the record stores in flight)
+    ColCursor cc;      // the FlexGate column layout of a direct cell (flat stream: the identity, never located)
     HF void rec(int t, uint64_t a, uint64_t b, uint64_t c, uint64_t d) { g_store_rec(recs + nrec, a, b, c, d); nrec++; cell_off += ncells[t]; }
-    HF void cell(const fr_t &v) { g_store_fr(out + cell_off, v); cell_off++; }
+    HF void cell(const fr_t &v) { g_store_fr(out + cc.map(cell_off), v); cell_off++; }
     HF void gate() {} HF void lookup() {}
     HF void skip(uint64_t nr, uint64_t nc) { nrec += nr; cell_off += nc; }
     HF void merkle_begin(int, int, bool, uint64_t) {} HF void merkle_end(int, int, bool) {} HF void query_begin(int, uint64_t) {} HF void query_end(int, uint64_t) {}
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64) __attribute__((flatten)) void k_replay(ReplayAr
     const uint32_t p = g / ninst, inst = g % ninst;
     const InstD *const I = R.insts + inst0 + inst;
     const uint32_t imp0 = I->imp0, in0 = I->in0;
-    ReplaySink sink; sink.recs = R.recs + (uint64_t)p * R.rec_stride; sink.out = R.out + (uint64_t)p * R.cell_stride; sink.ncells = s_nc;
+    ReplaySink sink; sink.recs = R.recs + (uint64_t)p * R.rec_stride; sink.out = R.out + (uint64_t)p * R.cell_stride; sink.ncells = s_nc; sink.cc.init(R.cm);
     sink.nrec = I->rec0; sink.cell_off = I->cell0;
     ValCfg cfg; cfg.proof = R.proofs + (uint64_t)p * R.proof_words; cfg.mode = 1; cfg.L = R.L; cfg.P = R.P; cfg.inv_pos = R.inv_pos; cfg.inv_neg = R.inv_neg; cfg.st = nullptr;
     cfg.split = false; cfg.split_bn = false; cfg.load_items = nullptr; cfg.n_load_items = 0; cfg.load_nrec = cfg.load_ncell = 0; cfg.n_cap_items = 0; cfg.fri = nullptr;
@@ -258,7 +259,7 @@ using namespace h2w;
 
 namespace h2w {
 uint64_t traced_workspace_bytes(const h2w_plan *p, uint64_t n);
-int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_);
+int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, ColMap cm, uint64_t cell_stride);
 void traced_free(h2w_plan *p);
 struct TracedWs { size_t recs, status, lflag, ctr, vals, total; };
 static size_t al(size_t x) { return (x + 255) / 256 * 256; }
@@ -278,7 +279,7 @@ void traced_free(h2w_plan *p) {
     if (t->d_inputs) (void)hipFree(t->d_inputs); if (t->d_pool64) (void)hipFree(t->d_pool64); if (t->d_poolfr) (void)hipFree(t->d_poolfr);
     delete t; p->traced = nullptr;
 }
-int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_) {
+int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void *advice_dev, void *workspace_dev, void *stream_, ColMap cm, uint64_t cell_stride) {
     TracedPlan *t = p->traced;
     if (n_proofs > 65535) { set_error("h2w_fri_witness_batch: more than 65535 proofs per call"); return -1; }
     DeviceGuard dg(p->device);
@@ -286,7 +287,7 @@ int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void 
     const TracedWs wl = traced_ws(p, n_proofs); char *ws = (char *)workspace_dev;
     ReplayArgs R; memset(&R, 0, sizeof(R));
     R.tape = t->d_tape; R.insts = t->d_insts; R.imps = t->d_imps; R.inputs = t->d_inputs; R.pool64 = t->d_pool64; R.poolfr = t->d_poolfr;
-    R.proofs = proofs_dev; R.proof_words = p->pl.total; R.recs = (rec_t *)(ws + wl.recs); R.rec_stride = p->nrec; R.out = (fr_t *)advice_dev; R.cell_stride = p->ncells;
+    R.proofs = proofs_dev; R.proof_words = p->pl.total; R.recs = (rec_t *)(ws + wl.recs); R.rec_stride = p->nrec; R.out = (fr_t *)advice_dev; R.cell_stride = cell_stride; R.cm = cm;      // (cm.starts: the FlexGate columns of every proof, cell_stride = ncols << k; else the flat stream)
     R.vals = (uint64_t *)(ws + wl.vals); R.status = (uint32_t *)(ws + wl.status); R.ncells = p->d_ncells; R.inv_pos = p->d_inv; R.inv_neg = p->d_inv + INV_TAB; R.P = p->P; R.L = p->shape.lookup_bits;
     R.nproofs = (uint32_t)n_proofs;
     R.ntmpl = (uint32_t)t->tmpls.size(); R.tm = t->d_tm; R.prefix = t->d_prefix; R.npool64 = t->npool64; R.npoolfr = t->npoolfr;
@@ -301,7 +302,7 @@ int traced_run(h2w_plan *p, const uint64_t *proofs_dev, uint64_t n_proofs, void 
     }
     // expansion of the block records
     ExpandArgs E;
-    E.meta = p->d_meta; E.recs = R.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = R.out; E.cell_stride = p->ncells; E.pool = nullptr; E.cm = ColMap{nullptr, 0, 0};
+    E.meta = p->d_meta; E.recs = R.recs; E.nrec = p->nrec; E.rec_stride = p->nrec; E.out = R.out; E.cell_stride = cell_stride; E.pool = nullptr; E.cm = cm;
     expand_unsharded(E); p->dt.fill(E);
     E.tile_ctr = (uint32_t *)(ws + wl.ctr); E.roam_per_cu = 2;
     H2W_HIP(hipMemsetAsync(E.tile_ctr, 0, n_proofs * 4, stream));

@@ -95,3 +95,42 @@ def test_replay_reports_the_reference_panics_as_status_words(h2w, h2w_api, oracl
         out.append((pl.status(ws.data_ptr(), n, st), adv.cpu().numpy().tobytes()))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     plan.close(); ref.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_replay_writes_the_flexgate_columns(h2w, h2w_api, oracle, consts, mode):
+    """h2w_fri_witness_batch_columns on a traced plan: the recorded run replayed straight into the FlexGate column layout (direct cells through the column cursor,
+    block records through the column form of the expansion kernel, boundary rows repeated by the fix-up kernel) - the columns the compiled plan of the same shape
+    writes for the same proofs (tests/test_layout_metadata.py pins those to the oracle's relayout), at two column heights."""
+    import numpy as np
+    import torch
+    ko, kh = consts
+    args = (7, 3, 2, mode)
+    sh = h2w.fibonacci_shape(*args[:2], rate_bits=args[2], hash_mode=args[3]); osh = oracle.fibonacci_shape(*args[:2], rate_bits=args[2], hash_mode=args[3])
+    proofs = [oracle.synth_proof(osh, s) for s in (31, 32, 33)]
+    ctx = h2w_api.Context(21, True, 0)
+    ctx.trace_begin()
+    h2w_api.verify_stark(ctx, sh, kh, np.frombuffer(bytes(proofs[0]), dtype=np.uint64))
+    traced = h2w_api.Plan.from_trace(ctx, len(proofs[0])); ctx.close()
+    compiled = h2w_api.Plan(sh, kh)
+    assert traced.num_cells == compiled.num_cells
+    n = len(proofs)
+    host = torch.empty(n * compiled.proof_words, dtype=torch.int64)
+    for i, p in enumerate(proofs):
+        host[i * compiled.proof_words:(i + 1) * compiled.proof_words] = torch.frombuffer(bytearray(bytes(p)), dtype=torch.int64)
+    d_proofs = host.cuda(); st = torch.cuda.current_stream().cuda_stream
+    for k in (14, 17):
+        bp = compiled.break_points(k); ncol = len(bp) + 1
+        want = torch.full((((n * ncol) << k) * 32,), 0x5A, dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(compiled.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        compiled.run_columns(d_proofs.data_ptr(), n, bp, k, want.data_ptr(), ws.data_ptr(), st)
+        got = torch.full((((n * ncol) << k) * 32,), 0xA5, dtype=torch.uint8, device="cuda")          # poisoned: every row is written or zero-filled
+        ws2 = torch.zeros(traced.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        traced.run_columns(d_proofs.data_ptr(), n, bp, k, got.data_ptr(), ws2.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert compiled.status(ws.data_ptr(), n, st) == [0] * n and traced.status(ws2.data_ptr(), n, st) == [0] * n
+        if not torch.equal(want, got):
+            a = want.cpu().numpy().view(np.uint64).reshape(-1, 4); b = got.cpu().numpy().view(np.uint64).reshape(-1, 4)
+            bad = np.nonzero((a != b).any(axis=1))[0]; rows = 1 << k
+            raise AssertionError(f"k={k}: {len(bad)} cells differ; first (proof, col, row) = {[(int(i) // (ncol * rows), (int(i) // rows) % ncol, int(i) % rows) for i in bad[:6]]} got {b[bad[0]]} want {a[bad[0]]}")
+    traced.close(); compiled.close()
